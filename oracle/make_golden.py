@@ -1,0 +1,371 @@
+"""TEST INFRASTRUCTURE — mints golden vectors from the REFERENCE (build container only).
+
+    python -m oracle.make_golden            # writes tests/golden/*.npz
+
+Imports /root/reference through oracle/ref_shim.py, runs the reference's own modules /
+assigner / losses / postprocess on small seeded inputs with explicit weights and stores
+inputs + expected outputs (fixtures are data only: no reference source text is stored).
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_shim as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}/{kk}"] = _np(vv)
+        elif isinstance(v, (list, tuple)):
+            for j, vv in enumerate(v):
+                flat[f"{k}/{j}"] = _np(vv)
+        else:
+            flat[k] = _np(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KB, {len(flat)} arrays")
+
+
+def set_bn(m, gen):
+    """initialize_weights semantics (eps/momentum) + randomised affine/running stats."""
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eps, mod.momentum = 1e-3, 0.03
+            with torch.no_grad():
+                mod.weight.copy_(1.0 + 0.2 * (torch.rand(mod.weight.shape, generator=gen) - 0.5))
+                mod.bias.copy_(0.2 * (torch.rand(mod.bias.shape, generator=gen) - 0.5))
+                mod.running_mean.copy_(0.1 * (torch.rand(mod.bias.shape, generator=gen) - 0.5))
+                mod.running_var.copy_(1.0 + 0.5 * torch.rand(mod.bias.shape, generator=gen))
+        if isinstance(mod, (torch.nn.SiLU,)):
+            mod.inplace = True
+
+
+def module_fixture(name, m, x, prefix="model.0", extra=None, keep_grads=None):
+    """train fwd/bwd + eval fwd of one reference module with explicit weights."""
+    gen = torch.Generator().manual_seed(123)
+    set_bn(m, gen)
+    sd0 = {f"{prefix}.{k}": v.clone() for k, v in m.state_dict().items()}
+    m.train()
+    xin = x.clone().requires_grad_(True)
+    y = m(xin)
+    r = torch.rand(y.shape, generator=gen) - 0.5
+    (y * r).sum().backward()
+    grads = {f"{prefix}.{k}": p.grad.clone() for k, p in m.named_parameters() if p.grad is not None
+             and (keep_grads is None or any(t in k for t in keep_grads))}
+    sd1 = {f"{prefix}.{k}": v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    m.eval()
+    with torch.no_grad():
+        ye = m(x.clone())
+    save(name, x=x, r=r, y_train=y, dx=xin.grad, y_eval=ye, state=sd0, state_after=sd1, grads=grads, **(extra or {}))
+
+
+def synth_batch(B, H, W, nmax, gen, nc=3):
+    """SURVEY §8d synthetic GT recipe (seeded)."""
+    rows = []
+    for b in range(B):
+        n = int(torch.randint(1, nmax + 1, (1,), generator=gen))
+        for _ in range(n):
+            rows.append(b)
+    n = len(rows)
+    bi = torch.tensor(rows, dtype=torch.float32)
+    cls = torch.randint(0, nc, (n, 1), generator=gen).float()
+    cxy = 0.2 + 0.6 * torch.rand(n, 2, generator=gen)
+    wh = 0.05 + 0.25 * torch.rand(n, 2, generator=gen)
+    bboxes = torch.cat((cxy, wh), 1)
+    scale = torch.tensor([W, H], dtype=torch.float32)
+    c2 = cxy * scale
+    s2 = wh * scale
+    c3 = c2 + 2.0 * torch.randn(n, 2, generator=gen)
+    return {
+        "batch_idx": bi, "cls": cls, "bboxes": bboxes, "center_2d": c2, "size_2d": s2, "center_3d": c3,
+        "size_3d": 0.1 * torch.randn(n, 3, generator=gen), "depth": 5 + 55 * torch.rand(n, generator=gen),
+        "heading_bin": torch.randint(0, 12, (n,), generator=gen).float(),
+        "heading_res": (torch.rand(n, generator=gen) - 0.5) * (np.pi / 6),
+        "calib": torch.tensor([[W / 2, H / 2, 700.0, 700.0, 0.06, -0.002]]).repeat(B, 1),
+        "mean_sizes": torch.tensor([[1.76255119, 0.66068622, 0.84422524], [1.52563191, 1.62856739, 3.88311640],
+                                    [1.73698127, 0.59706367, 1.76282397]]),
+        "mixed": torch.zeros(B, dtype=torch.uint8),
+    }
+
+
+TINY3D = {
+    "nc": 3, "scales": {"n": [0.33, 0.125, 1024]}, "scale": "n",
+    "dsconv": False, "use_predecessors": False, "detach_predecessors": False, "deform": False, "common_head": False,
+    "num_scales": 3, "half_channels": False, "fgdm_predictor": False, "kernel_size_1": 3, "kernel_size_2": 3,
+    "channels": {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")},
+}
+
+
+def tiny_cfg(ref_rel, **over):
+    d = R.load_yaml(ref_rel)
+    d = {k: v for k, v in d.items() if k in ("backbone", "head")}
+    d.update(copy.deepcopy(TINY3D))
+    d.update(over)
+    return d
+
+
+def main():
+    R.import_reference()
+    from ultralytics.nn.modules import Conv, C2f, C2fCIB, SCDown, SPPF, PSA
+    from ultralytics.nn.modules.head import v10Detect3d, v10Detect
+    from ultralytics.utils.tal import TaskAlignedAssigner, TaskAlignedAssigner3d, make_anchors
+    from ultralytics.utils import ops as ref_ops
+    from ultralytics.utils.loss import DetectLoss3d, v10DetectLoss
+    from ultralytics.utils.torch_utils import fuse_conv_and_bn
+
+    g = torch.Generator().manual_seed(7)
+
+    # ---- a1/a2 Conv variants ------------------------------------------------------------
+    for name, args, shape in [
+        ("conv_k1", (16, 24, 1, 1), (2, 16, 12, 12)),
+        ("conv_k3s1", (16, 24, 3, 1), (2, 16, 12, 12)),
+        ("conv_k3s2", (16, 24, 3, 2), (2, 16, 12, 12)),
+        ("conv_k3s2_odd", (8, 16, 3, 2), (2, 8, 13, 11)),
+        ("conv_stem", (3, 16, 3, 2), (2, 3, 16, 16)),
+        ("conv_dw3", (16, 16, 3, 1, None, 16), (2, 16, 12, 12)),
+        ("conv_dw3s2", (16, 16, 3, 2, None, 16, 1, False), (2, 16, 12, 12)),
+        ("conv_dw7", (16, 16, 7, 1, 3, 16, 1, False), (2, 16, 12, 12)),
+        ("conv_k1_noact", (16, 24, 1, 1, None, 1, 1, False), (2, 16, 12, 12)),
+    ]:
+        torch.manual_seed(1)
+        module_fixture(name, Conv(*args), torch.randn(*shape, generator=g))
+
+    # ---- a4-a8 blocks ---------------------------------------------------------------------
+    torch.manual_seed(2)
+    module_fixture("c2f_shortcut", C2f(32, 32, 2, True), torch.randn(2, 32, 10, 10, generator=g))
+    torch.manual_seed(3)
+    module_fixture("c2f_neck", C2f(48, 32, 1, False), torch.randn(2, 48, 10, 10, generator=g))
+    torch.manual_seed(4)
+    module_fixture("c2fcib_lk", C2fCIB(32, 32, 1, True, True), torch.randn(2, 32, 10, 10, generator=g))
+    torch.manual_seed(5)
+    module_fixture("c2fcib", C2fCIB(32, 32, 1, True, False), torch.randn(2, 32, 10, 10, generator=g))
+    torch.manual_seed(6)
+    module_fixture("scdown", SCDown(16, 32, 3, 2), torch.randn(2, 16, 12, 12, generator=g))
+    torch.manual_seed(7)
+    module_fixture("sppf", SPPF(32, 32, 5), torch.randn(2, 32, 9, 9, generator=g))
+    torch.manual_seed(8)
+    module_fixture("psa_1head", PSA(128, 128), torch.randn(2, 128, 6, 5, generator=g))
+    torch.manual_seed(9)
+    module_fixture("psa_2head", PSA(256, 256), torch.randn(1, 256, 5, 5, generator=g), keep_grads=("attn.qkv", "attn.pe", "cv1.bn"))
+
+    # ---- a20 BN folding --------------------------------------------------------------------
+    torch.manual_seed(10)
+    c = Conv(8, 12, 3, 1)
+    set_bn(c, g)
+    f = fuse_conv_and_bn(c.conv, c.bn)
+    save("fold_bn", w=c.conv.weight, gamma=c.bn.weight, beta=c.bn.bias, mean=c.bn.running_mean, var=c.bn.running_var,
+         w_folded=f.weight, b_folded=f.bias)
+
+    # ---- a9/a10 v10Detect3d train + eval ------------------------------------------------------
+    ch = (16, 32, 64)
+    chan = {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    for tag, k1, k2, nl in (("k33", 3, 3, 3), ("k31", 3, 1, 2)):
+        torch.manual_seed(11)
+        hd = v10Detect3d(3, ch, False, chan, False, False, False, False, nl, False, False, k1, k2)
+        hd.stride = torch.tensor([8.0, 16.0, 32.0][:nl])
+        hd.bias_init()
+        set_bn(hd, g)
+        # make o2o and o2m differ
+        with torch.no_grad():
+            for p_ in hd.o2m_heads.parameters():
+                p_.add_(0.01 * torch.randn(p_.shape, generator=g))
+        sd = {f"model.0.{k}": v.clone() for k, v in hd.state_dict().items() if k.startswith(("o2o_heads.", "o2m_heads."))}
+        xs = [torch.randn(2, ch[i], s, s, generator=g) for i, s in enumerate((16, 8, 4))]
+        hd.train()
+        xin = [x.clone().requires_grad_(True) for x in xs]
+        out = hd(xin)
+        rs = [torch.rand(t.shape, generator=g) - 0.5 for t in out["one2many"] + out["one2one"]]
+        sum((t * r).sum() for t, r in zip(out["one2many"] + out["one2one"], rs)).backward()
+        grads = {f"model.0.{k}": p.grad.clone() for k, p in hd.named_parameters()
+                 if p.grad is not None and k.startswith(("o2o_heads.", "o2m_heads.")) and k.split(".")[1] in ("0", "6")}
+        save(f"head3d_train_{tag}", x=xs, r=rs, o2m=out["one2many"], o2o=out["one2one"], o2m_embs=out["o2m_embs"][:nl],
+             o2o_embs=out["o2o_embs"][:nl], dx=[x.grad for x in xin[:nl]], state=sd, grads=grads,
+             meta=np.array([k1, k2, nl]))
+        # eval on a deep copy (padding mutation); every level needs >= 50 cells
+        he = copy.deepcopy(hd).eval()
+        xe = [torch.randn(2, ch[i], s, s, generator=g) for i, s in enumerate((32, 16, 8))]
+        with torch.no_grad():
+            oe = he(xe)
+        y, maps = oe["one2one"]
+        sde = {f"model.0.{k}": v.clone() for k, v in he.state_dict().items() if k.startswith("o2o_heads.")}
+        save(f"head3d_eval_{tag}", x=xe, y=y, maps=maps, state=sde, meta=np.array([k1, k2, nl]))
+
+    # ---- a14 assigners ------------------------------------------------------------------------
+    B, shapes, strides = 2, [(16, 16), (8, 8), (4, 4)], [8.0, 16.0, 32.0]
+    A = sum(h * w for h, w in shapes)
+    feats = [torch.zeros(B, 1, h, w) for h, w in shapes]
+    anc, st = make_anchors(feats, strides, 0.5)
+    batch = synth_batch(B, 128, 128, 5, g)
+    from ultralytics.utils.loss import DDDetectionLoss, v8DetectionLoss  # noqa
+    for topk in (8, 1):
+        ps = torch.rand(B, A, 3, generator=g) * 0.3
+        off = torch.randn(B, A, 2, generator=g) * 0.5
+        siz = 2.0 + 6.0 * torch.rand(B, A, 2, generator=g)
+        cen = anc + off
+        pb = torch.cat((cen - siz / 2, cen + siz / 2), -1) * st
+        p3 = torch.cat((torch.randn(B, A, 2, generator=g) * 0.3, torch.randn(B, A, 3, generator=g) * 0.1,
+                        torch.randn(B, A, 24, generator=g), 10 + 40 * torch.rand(B, A, 1, generator=g),
+                        torch.randn(B, A, 1, generator=g)), -1)
+        # padded gt tensor exactly as the reference loss builds it (loss.py:848-857)
+        rows = torch.cat((batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"], batch["center_2d"],
+                          batch["size_2d"], batch["center_3d"], batch["size_3d"], batch["depth"].view(-1, 1),
+                          batch["heading_bin"].view(-1, 1), batch["heading_res"].view(-1, 1)), 1)
+        helper = DDDetectionLoss.__new__(DDDetectionLoss)
+        helper.device = torch.device("cpu")
+        gt = helper.preprocess(rows, B, torch.tensor([128.0, 128.0, 128.0, 128.0]))
+        gts = gt.split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)
+        mask_gt = gts[1].sum(2, keepdim=True).gt_(0)
+        asg = TaskAlignedAssigner3d(topk=topk, num_classes=3, alpha=0.5, beta=1.0, gamma=1.0, use_2d=True, use_3d=True,
+                                    kps_dist_metric="l1", constrain_anchors=True)
+        targets, fg, gi, pkps, gkps = asg(ps, pb, p3, anc * st, gts, mask_gt, st, batch["calib"], batch["mean_sizes"])
+        save(f"tal3d_topk{topk}", pd_scores=ps, pd_bboxes=pb, pd_3d=p3, anc=anc, stride=st, gt=gt, mask_gt=mask_gt,
+             calib=batch["calib"], mean_sizes=batch["mean_sizes"], fg_mask=fg, target_gt_idx=gi, targets=targets,
+             pd_kps=pkps, gt_kps=gkps)
+    for topk in (10, 1):
+        ps = torch.rand(B, A, 80, generator=g) * 0.3
+        lt = 0.5 + 3 * torch.rand(B, A, 2, generator=g)
+        rb = 0.5 + 3 * torch.rand(B, A, 2, generator=g)
+        pb = torch.cat((anc - lt, anc + rb), -1) * st
+        rows = torch.cat((batch["batch_idx"].view(-1, 1), (batch["cls"] * 20).view(-1, 1), batch["bboxes"]), 1)
+        helper = v8DetectionLoss.__new__(v8DetectionLoss)
+        helper.device = torch.device("cpu")
+        gt = helper.preprocess(rows, B, torch.tensor([128.0, 128.0, 128.0, 128.0]))
+        gl, gb = gt.split((1, 4), 2)
+        mask_gt = gb.sum(2, keepdim=True).gt_(0)
+        asg = TaskAlignedAssigner(topk=topk, num_classes=80, alpha=0.5, beta=6.0)
+        tl, tb, ts, fg, gi = asg(ps, pb, anc * st, gl, gb, mask_gt)
+        save(f"tal2d_topk{topk}", pd_scores=ps, pd_bboxes=pb, anc=anc, stride=st, gt=gt, mask_gt=mask_gt,
+             fg_mask=fg, target_gt_idx=gi, target_labels=tl, target_bboxes=tb, target_scores=ts)
+
+    # ---- a17/a18 losses (values + grads wrt head maps) ---------------------------------------------
+    class _M:  # minimal stand-in exposing what the reference losses read from `model`
+        pass
+
+    def fake_model(head, args):
+        m = _M()
+        m.args = args
+        m.model = [head]
+        m.parameters = lambda: iter([torch.zeros(1)])
+        return m
+
+    hd3 = v10Detect3d(3, ch, False, chan, False, False, False, False, 3, False, False, 3, 3)
+    hd3.stride = torch.tensor(strides)
+    crit = DetectLoss3d(fake_model(hd3, R.model_args()))
+    o2m = [torch.randn(B, 38, h, w, generator=g).requires_grad_(True) for h, w in shapes]
+    o2o = [torch.randn(B, 38, h, w, generator=g).requires_grad_(True) for h, w in shapes]
+    for t in o2m + o2o:  # plausible depth / size channels
+        with torch.no_grad():
+            t[:, 36] = 10 + 30 * torch.rand(t[:, 36].shape, generator=g)
+            t[:, 5:7] = 2 + 4 * torch.rand(t[:, 5:7].shape, generator=g)
+            t[:, 0:3] -= 2.0
+    with R.cpu_cuda_noop():
+        loss, items = crit({"one2many": o2m, "one2one": o2o, "o2m_embs": None, "o2o_embs": None}, batch)
+    loss.backward()
+    save("loss3d", o2m=o2m, o2o=o2o, batch=batch, loss=loss, items=items, g_o2m=[t.grad for t in o2m],
+         g_o2o=[t.grad for t in o2o], strides=np.array(strides))
+
+    hd2 = v10Detect(80, ch)
+    hd2.stride = torch.tensor(strides)
+    crit2 = v10DetectLoss(fake_model(hd2, R.model_args()))
+    o2m = [torch.randn(B, 144, h, w, generator=g).requires_grad_(True) for h, w in shapes]
+    o2o = [torch.randn(B, 144, h, w, generator=g).requires_grad_(True) for h, w in shapes]
+    b2 = dict(batch)
+    b2["cls"] = batch["cls"] * 20
+    loss, items = crit2({"one2many": o2m, "one2one": o2o}, b2)
+    loss.backward()
+    save("loss2d", o2m=o2m, o2o=o2o, batch=b2, loss=loss, items=items, g_o2m=[t.grad for t in o2m],
+         g_o2o=[t.grad for t in o2o], strides=np.array(strides))
+
+    # ---- a19 postprocess ---------------------------------------------------------------------------
+    p3 = torch.randn(2, A, 38, generator=g)
+    reg, sc, lab = ref_ops.v10_3Dpostprocess(p3, 50, 3)
+    save("post3d", preds=p3, reg=reg, scores=sc, labels=lab)
+    p2 = torch.cat((torch.rand(2, A, 4, generator=g) * 100, torch.rand(2, A, 80, generator=g)), -1)
+    bx, sc, lab = ref_ops.v10postprocess(p2, 300, 80)
+    save("post2d", preds=p2, boxes=bx, scores=sc, labels=lab)
+
+    # ---- end-to-end tiny models (whole graph: parse + forward + loss + backward) ------------------------
+    for tag, rel, H in (("e2e_tiny3d_s", "v10-3D/yolov10s_3D.yaml", 64), ("e2e_tiny3d_m", "v10-3D/yolov10m_3D.yaml", 64)):
+        cfg = tiny_cfg(rel)
+        if tag.endswith("_m"):
+            cfg.update(num_scales=2, kernel_size_2=1)
+        m = R.build_model(cfg, seed=0)
+        gen = torch.Generator().manual_seed(5)
+        set_bn(m, gen)
+        with torch.no_grad():
+            for p_ in m.model[-1].o2m_heads.parameters():
+                p_.add_(0.01 * torch.randn(p_.shape, generator=gen))
+        sd = {k: v.clone() for k, v in m.state_dict().items() if ".o2o_heads." in k or ".o2m_heads." in k or not k.startswith(f"model.{len(m.model) - 1}.")}
+        img = torch.rand(2, 3, H, H, generator=gen)
+        bt = synth_batch(2, H, H, 3, gen)
+        bt["img"] = img
+        m.train()
+        with R.cpu_cuda_noop():
+            loss, items = m(bt)
+        loss.backward()
+        names = dict(m.named_parameters())
+        gsel = {k: names[k].grad.clone() for k in list(names)[:12] + [k for k in names if ".o2m_heads.6." in k][:6]}
+        after = {k: v.clone() for k, v in m.state_dict().items() if ("running" in k or "num_batches" in k) and k in sd}
+        me = copy.deepcopy(m).eval()
+        H2 = 256
+        img2 = torch.rand(1, 3, H2, H2, generator=gen)
+        with torch.no_grad():
+            oe = me(img2)["one2one"][0]
+        reg, sc, lab = ref_ops.v10_3Dpostprocess(oe.permute(0, 2, 1), 50, 3)
+        cfg_arrays = {"width": np.array(0.125)}
+        save(tag, img=img, batch={k: v for k, v in bt.items() if k != "img"}, loss=loss, items=items.detach(), state=sd,
+             grads=gsel, state_after=after, img_eval=img2, y_eval=oe, post_reg=reg, post_scores=sc, post_labels=lab,
+             strides=m.stride, **cfg_arrays)
+
+    # tiny 2D model (config C1 family)
+    cfg = R.load_yaml("v10/yolov10n.yaml")
+    cfg = {k: v for k, v in cfg.items() if k in ("backbone", "head")}
+    cfg.update(nc=20, scales={"n": [0.33, 0.125, 1024]}, scale="n")
+    m = R.build_model(cfg, seed=0)
+    gen = torch.Generator().manual_seed(6)
+    set_bn(m, gen)
+    last = len(m.model) - 1
+    with torch.no_grad():
+        for n_, p_ in m.model[-1].named_parameters():
+            if n_.startswith("one2one"):
+                p_.add_(0.01 * torch.randn(p_.shape, generator=gen))
+    img = torch.rand(2, 3, 64, 64, generator=gen)
+    bt = synth_batch(2, 64, 64, 3, gen)
+    bt["cls"] = bt["cls"] * 5
+    bt["img"] = img
+    m.train()
+    loss, items = m(bt)
+    loss.backward()
+    names = dict(m.named_parameters())
+    gsel = {k: names[k].grad.clone() for k in list(names)[:6] if names[k].grad is not None}
+    me = copy.deepcopy(m).eval()
+    with torch.no_grad():
+        oe = me(img)
+    after2d = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    save("e2e_tiny2d", state_after=after2d, img=img, batch={k: v for k, v in bt.items() if k in ("batch_idx", "cls", "bboxes")}, loss=loss,
+         items=items, state={k: v.clone() for k, v in m.state_dict().items()}, grads=gsel,
+         y_eval_o2o=oe["one2one"][0], y_eval_o2m=oe["one2many"][0], strides=m.stride)
+
+
+if __name__ == "__main__":
+    main()
