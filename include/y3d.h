@@ -1,0 +1,156 @@
+/* y3d.h — C ABI of liby3d_hip.so: the MI355X (gfx950) kernels of the YOLOv10 / YOLOv10-3D hot path.
+ *
+ * The reference (baldhat/yolov10-3D) has no native layer: every entry point below replaces a
+ * *torch op call site* inside one of the reference's nn.Modules / loss functions (file:line cited
+ * per function, paths relative to ultralytics/).  The host-side mirror of those modules
+ * (yolov10-3d_amd/modules.py, loss.py) binds this library through ctypes; INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - all tensors are device pointers; activations are NHWC ("channels last"): element (b,h,w,c) of a
+ *     tensor with strides (sb, sh, sw) lives at  ptr + b*sb + h*sh + w*sw + c   (strides in ELEMENTS).
+ *     "pixel-dense" tensors only carry `sw` (pixel stride; sh = W*sw, sb = H*W*sw) so they may be
+ *     channel slices of a wider buffer (concat-free writes).
+ *   - dtype: Y3D_F32 (exact-f32 MFMA / fp32 VALU; the parity mode) or Y3D_BF16 (bf16 storage + bf16 MFMA,
+ *     fp32 accumulation / statistics / loss math; the performance mode).
+ *   - 16-byte chunks: channel counts, channel offsets and strides of activation tensors must be
+ *     multiples of 4 (f32) / 8 (bf16) elements unless a function says otherwise.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Nothing here allocates, frees or synchronises:
+ *     every call is capturable into a hipGraph.
+ *   - return value: Y3D_OK or a negative Y3D_ERR_*; y3d_last_error() gives the message
+ *     (the host mirror raises it as a Python exception — the reference's error behaviour).
+ */
+#ifndef Y3D_H
+#define Y3D_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { Y3D_F32 = 0, Y3D_BF16 = 1 };
+enum { Y3D_OK = 0, Y3D_ERR_INVALID = -1, Y3D_ERR_HIP = -2 };
+
+const char* y3d_last_error(void);
+int y3d_abi_version(void);
+/* name of the device the library would launch on, its CU count and LDS bytes per workgroup (sanity / roofline) */
+int y3d_device_info(char* name, int name_len, int* compute_units, int* lds_bytes, int* clock_khz);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense / grouped convolution, implicit GEMM on MFMA (conv_gemm.hip)
+ * replaces nn.Conv2d.forward + autograd backward at nn/modules/conv.py:115,120-122 (Conv),
+ * head.py:633-637 (3D head branches), block.py:225-226,336-337 (C2f / Bottleneck), ...
+ * ---------------------------------------------------------------------------------------------- */
+/* OIHW fp32 parameter -> K-contiguous compute-dtype layout [Cout][kh*kw][Cin_g_pad] */
+int y3d_pack_weight_fwd(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int Cin_g_pad, int kh, int kw, void* stream);
+/* OIHW fp32 parameter -> [G][Cin_g][kh*kw][Cout_g] (row pitch y3d_conv_kpad(dtype, kh*kw*Cout_g)) for the data gradient */
+int y3d_pack_weight_dgrad(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int groups, int kh, int kw, void* stream);
+int y3d_conv_kpad(int dtype, int k_total);
+/* number of BatchNorm partial rows the forward emits: ceil(B*Ho*Wo / 128) */
+int y3d_conv_stat_blocks(int B, int Ho, int Wo);
+/* y = conv(x, w) (+bias).  stat_partials (optional, no bias): [y3d_conv_stat_blocks][Cout][2] = per-block (sum, sum^2) of y. */
+int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                   const void* w_packed, const float* bias, void* y, int64_t ysw, int Ho, int Wo, int Cout, int groups,
+                   int kh, int kw, int stride, int pad, float* stat_partials, void* stream);
+/* dx = conv_transpose(dy, w)  (F.conv2d backward w.r.t. input) */
+int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
+                        const void* w_packed_dgrad, void* dx, int64_t xsw, int H, int W, int Cin, int groups, int kh, int kw,
+                        int stride, int pad, void* stream);
+/* split-K factor the weight gradient wants; slab must hold nsplit*Cout*kh*kw*Cin_g floats */
+int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_g, int groups, int kh, int kw);
+/* grad_oihw (+)= dL/dw.  Cin may be channel-padded (stem): only the first Cin_real channels are written. */
+int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                          int Cin_real, const void* dy, int64_t dsw, int Ho, int Wo, int Cout, int groups, int kh, int kw,
+                          int stride, int pad, float* slab, int nsplit, float* grad_oihw, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depth-wise convolution (dwconv.hip) — Conv(g=c): conv.py:172-177, block.py:705-706,747-751,783,824
+ * ---------------------------------------------------------------------------------------------- */
+int y3d_dw_blocks(int64_t M);  /* rows of BN partials / weight-gradient slabs for M output pixels */
+int y3d_dw_pack_weight(const float* w_oihw, float* out_taps_c, int C, int kh, int kw, void* stream);
+int y3d_dwconv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
+                     const float* w_packed, void* y, int64_t ysw, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                     float* stat_partials, void* stream);
+int y3d_dwconv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int C,
+                          const float* w_packed, void* dx, int64_t xsw, int H, int W, int kh, int kw, int stride, int pad,
+                          void* stream);
+/* slab: y3d_dw_blocks(B*Ho*Wo) * kh*kw*C floats */
+int y3d_dwconv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
+                            const void* dy, int64_t dsw, int Ho, int Wo, int kh, int kw, int stride, int pad, float* slab,
+                            float* grad_oihw, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm (batch or running statistics) + SiLU + residual (bn_act.hip)
+ * replaces nn.BatchNorm2d / nn.SiLU / `x + ...` at conv.py:106,118-122, block.py:342,711,758,816-817;
+ * eps / momentum semantics of utils/torch_utils.py:327-337
+ * ---------------------------------------------------------------------------------------------- */
+/* partials [nblk][C][2] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats
+ * updated in place (momentum, unbiased variance) when running_mean != NULL */
+int y3d_bn_finalize(const float* partials, int nblk, int C, int64_t count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                    float* shift, void* stream);
+int y3d_bn_eval_scale(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, void* stream);
+/* u = y*scale+shift (+res if res_mode==2); z = act ? silu(u) : u; (+res if res_mode==1) */
+int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, const float* shift, int act, int res_mode,
+                   const void* res, int64_t rsw, void* z, int64_t zsw, int64_t P, int C, void* stream);
+int y3d_bn_bwd_blocks(int64_t P);
+/* pass 1: partials [y3d_bn_bwd_blocks(P)][C][2] = (sum g, sum g*xhat), g = dz * act'(u) */
+int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,
+                          const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                          int res_mode, float* partials, int64_t P, int C, void* stream);
+/* dgamma/dbeta (+)= sums; mean_g, mean_gx = sums / count */
+int y3d_bn_bwd_finalize(const float* partials, int nblk, int C, int64_t count, float* dgamma, float* dbeta, int accumulate,
+                        float* mean_g, float* mean_gx, void* stream);
+/* pass 2: dy = scale*(g - mean_g - xhat*mean_gx) [train] or scale*g [eval]; dres = g for res_mode==2 */
+int y3d_bn_act_bwd_apply(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,
+                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* mean_g, const float* mean_gx, int act, int res_mode, int train, void* dy, int64_t dysw,
+                         void* dres, int64_t drsw, int64_t P, int C, void* stream);
+/* column sums of a [P][C] tensor as partials [y3d_bn_bwd_blocks(P)][C][2] (bias gradients; reduce with y3d_bn_bwd_finalize) */
+int y3d_colsum_partials(int dtype, const void* x, int64_t xsw, float* partials, int64_t P, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph glue (misc.hip)
+ * ---------------------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(k, 1, k//2) — SPPF block.py:171-178.  argmax: [B*H*W][C] uint8 tap index (may be NULL) */
+int y3d_maxpool_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, void* y, int64_t ysw, uint8_t* argmax,
+                    int B, int H, int W, int C, int k, void* stream);
+int y3d_maxpool_bwd(int dtype, const void* dy, int64_t dsw, const uint8_t* argmax, void* dx, int64_t xsw, int B, int H, int W,
+                    int C, int k, void* stream);
+/* nn.Upsample(None, 2, "nearest") — cfg/models/v10 and v10-3D yaml rows; x is (B,H,W,C), y is (B,2H,2W,C) */
+int y3d_upsample2x_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, void* y, int64_t ysw, int B, int H, int W,
+                       int C, void* stream);
+int y3d_upsample2x_bwd(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, void* dx, int64_t xsw, int B, int H,
+                       int W, int C, void* stream);
+/* torch.cat(dim=1) member copy — Concat conv.py:404, block.py:178,233,818: y[:, :C] = x over P pixels */
+int y3d_copy2d(int dtype, const void* x, int64_t xsw, void* y, int64_t ysw, int64_t P, int C, void* stream);
+int y3d_add2d(int dtype, const void* a, int64_t asw, const void* b, int64_t bsw, void* y, int64_t ysw, int64_t P, int C, void* stream);
+/* model boundary: reference tensors are NCHW fp32 (nn/tasks.py:93-95) */
+int y3d_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cpad, void* stream);
+int y3d_nhwc_to_nchw(int dtype, const void* x_nhwc, int64_t xsw, float* y_nchw, int B, int C, int H, int W, void* stream);
+/* head final nn.Conv2d(c, out, 1) with bias, out <= 24 — head.py:637 (3D branches: nc,2,2,2,3,24,1,1) */
+int y3d_proj_fwd(int dtype, const void* x, int64_t xsw, const float* w, const float* bias, void* y, int64_t ysw, int64_t P,
+                 int Cin, int Cout, void* stream);
+int y3d_proj_bwd_data(int dtype, const void* dy, int64_t dsw, const float* w, void* dx, int64_t xsw, int64_t P, int Cin, int Cout,
+                      void* stream);
+int y3d_proj_blocks(int64_t P);
+/* slab: y3d_proj_blocks(P)*Cout*Cin floats, bias_slab: y3d_proj_blocks(P)*Cout floats */
+int y3d_proj_bwd_weight(int dtype, const void* x, int64_t xsw, const void* dy, int64_t dsw, float* slab, float* bias_slab,
+                        float* grad_w, float* grad_b, int accumulate, int64_t P, int Cin, int Cout, void* stream);
+int y3d_slab_reduce(const float* slab, float* out, int nblk, int64_t n, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PSA attention core (attn.hip) — Attention.forward block.py:785-797
+ * qkv: (B, N, nh*(2kd+hd)) with per-head block [q|k|v]; out: (B, N, nh*hd); lse/delta: (B, nh, N) fp32
+ * ---------------------------------------------------------------------------------------------- */
+int y3d_attn_fwd(int dtype, const void* qkv, int64_t qsw, void* out, int64_t osw, float* lse, int B, int N, int nh, int kd, int hd,
+                 float scale, void* stream);
+int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64_t osw, const void* dout, int64_t dsw,
+                 const void* dv_extra, int64_t esw, const float* lse, float* delta, void* dqkv, int64_t gsw, int B, int N, int nh,
+                 int kd, int hd, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Y3D_H */

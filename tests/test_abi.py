@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library loads and exports every symbol include/y3d.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+import yolov10_3d_amd as y3d
+from yolov10_3d_amd import _lib
+
+
+def test_header_parses_and_library_exports_every_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 35
+    src = open(os.path.join(ROOT, "include", "y3d.h")).read()
+    declared = set(re.findall(r"\b(y3d_\w+)\s*\(", re.sub(r"/\*.*?\*/", " ", src, flags=re.S)))
+    assert declared == set(protos), declared ^ set(protos)
+    assert os.path.exists(_lib.LIB_PATH), "liby3d_hip.so missing: run __graft_entry__.build()"
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in y3d.h but not exported"
+
+
+def test_host_side_helpers_without_gpu():
+    L = y3d.lib()
+    assert L.abi_version() == 1
+    assert L.conv_stat_blocks(32, 80, 80) == 1600
+    assert L.conv_kpad(_lib.BF16, 27) == 32 and L.conv_kpad(_lib.F32, 27) == 28
+    assert 1 <= L.conv2d_wgrad_splits(_lib.BF16, 32, 80, 80, 128, 128, 1, 3, 3) <= 256
+
+
+def test_invalid_arguments_raise_python_exceptions():
+    L = y3d.lib()
+    with pytest.raises(y3d.Y3DError, match="dtype"):
+        L.conv2d_fwd(7, None, 0, 0, 0, 1, 8, 8, 8, None, None, None, 8, 8, 8, 8, 1, 3, 3, 1, 1, None, None)
+    with pytest.raises(y3d.Y3DError, match="multiple"):
+        L.conv2d_fwd(_lib.BF16, None, 0, 0, 0, 1, 8, 8, 3, None, None, None, 8, 8, 8, 8, 1, 3, 3, 1, 1, None, None)
+    with pytest.raises(y3d.Y3DError, match="unsupported head dims"):
+        L.attn_fwd(_lib.F32, None, 0, None, 0, None, 1, 4, 1, 16, 32, 1.0, None)
+
+
+def test_no_cpu_fallback():
+    import torch
+    from yolov10_3d_amd import modules as M
+    with pytest.raises(y3d.Y3DError):
+        M.Conv(8, 8, 3)(torch.randn(1, 8, 4, 4))

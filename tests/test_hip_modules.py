@@ -1,0 +1,266 @@
+"""GPU parity: the HIP modules (through the C ABI) against the golden vectors minted from the reference,
+and against the CPU oracle restatement on fresh seeded inputs.
+
+fp32 mode (exact-f32 MFMA) is held to 1e-3 relative on every output (north_star tolerance);
+bf16 mode (the performance mode) is held to a documented looser bound."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+import yolov10_3d_amd as y3d  # noqa: E402
+from yolov10_3d_amd import modules as M  # noqa: E402
+from oracle import restate as RS  # noqa: E402  (the checker)
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-6)).item()
+
+
+def check(a, b, tol, what=""):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = rel_err(a, b)
+    assert e <= tol, f"{what}: max-norm relative error {e:.3e} > {tol}"
+
+
+def load_into(mod, state, prefix="model.0."):
+    sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
+    missing, unexpected = mod.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("num_batches" in k or k.split(".")[0] in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un") for k in missing), missing
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    return mod.to(DEV)
+
+
+MODS = {
+    "conv_k1": lambda: M.Conv(16, 24, 1, 1), "conv_k3s1": lambda: M.Conv(16, 24, 3, 1), "conv_k3s2": lambda: M.Conv(16, 24, 3, 2),
+    "conv_k3s2_odd": lambda: M.Conv(8, 16, 3, 2), "conv_stem": lambda: M.Conv(3, 16, 3, 2),
+    "conv_dw3": lambda: M.Conv(16, 16, 3, 1, None, 16), "conv_dw3s2": lambda: M.Conv(16, 16, 3, 2, None, 16, 1, False),
+    "conv_dw7": lambda: M.Conv(16, 16, 7, 1, 3, 16, 1, False), "conv_k1_noact": lambda: M.Conv(16, 24, 1, 1, None, 1, 1, False),
+    "c2f_shortcut": lambda: M.C2f(32, 32, 2, True), "c2f_neck": lambda: M.C2f(48, 32, 1, False),
+    "c2fcib_lk": lambda: M.C2fCIB(32, 32, 1, True, True), "c2fcib": lambda: M.C2fCIB(32, 32, 1, True, False),
+    "scdown": lambda: M.SCDown(16, 32, 3, 2), "sppf": lambda: M.SPPF(32, 32, 5),
+    "psa_1head": lambda: M.PSA(128, 128), "psa_2head": lambda: M.PSA(256, 256),
+}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("name", sorted(MODS))
+def test_module_vs_reference_golden(name, dtype, tol):
+    y3d.set_compute_dtype(dtype)
+    g = load_golden(name)
+    mod = load_into(MODS[name](), g["state"]).train()
+    is_stem = name == "conv_stem"
+    x = g["x"].to(DEV).requires_grad_(not is_stem)
+    y = mod(x)
+    check(y, g["y_train"], tol, "y_train")
+    (y.float() * g["r"].to(DEV)).sum().backward()
+    gtol = tol * 3
+    if not is_stem:
+        check(x.grad, g["dx"], gtol, "dx")
+    named = dict(mod.named_parameters())
+    for k, gv in g["grads"].items():
+        check(named[k[len("model.0."):]].grad, gv, gtol, f"grad {k}")
+    sd = mod.state_dict()
+    for k, v in g["state_after"].items():
+        check(sd[k[len("model.0."):]].float(), v.float(), 1e-3 if dtype == torch.float32 else 3e-2, f"state {k}")
+    mod.eval()
+    with torch.no_grad():
+        ye = mod(g["x"].to(DEV))
+    check(ye, g["y_eval"], tol, "y_eval")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("tag", ["k33", "k31"])
+def test_head3d_train_vs_reference_golden(tag, dtype, tol):
+    y3d.set_compute_dtype(dtype)
+    g = load_golden(f"head3d_train_{tag}")
+    k1, k2, nl = [int(v) for v in g["meta"]]
+    chan = {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    hd = M.v10Detect3d(3, (16, 32, 64), False, chan, False, False, False, False, nl, False, False, k1, k2)
+    hd.stride = torch.tensor([8.0, 16.0, 32.0][:nl])
+    hd = load_into(hd, g["state"]).train()
+    xs = [x.to(DEV).requires_grad_(True) for x in g["x"]]
+    out = hd(xs)
+    for a, b in zip(out["one2many"] + out["one2one"], g["o2m"] + g["o2o"]):
+        check(a, b, tol, "head map")
+    for a, b in zip(out["o2m_embs"], g["o2m_embs"]):
+        check(a, b, tol, "embs")
+    sum((t.float() * r.to(DEV)).sum() for t, r in zip(out["one2many"] + out["one2one"], g["r"])).backward()
+    for a, b in zip(xs[:nl], g["dx"]):
+        check(a.grad, b, tol * 3, "dx")
+    named = dict(hd.named_parameters())
+    for k, gv in g["grads"].items():
+        check(named[k[len("model.0."):]].grad, gv, tol * 3, f"grad {k}")
+
+
+@pytest.mark.parametrize("tag", ["k33", "k31"])
+def test_head3d_eval_vs_reference_golden(tag):
+    y3d.set_compute_dtype(torch.float32)
+    g = load_golden(f"head3d_eval_{tag}")
+    k1, k2, nl = [int(v) for v in g["meta"]]
+    chan = {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    hd = M.v10Detect3d(3, (16, 32, 64), False, chan, False, False, False, False, nl, False, False, k1, k2)
+    hd.stride = torch.tensor([8.0, 16.0, 32.0][:nl])
+    hd = load_into(hd, g["state"]).eval()
+    with torch.no_grad():
+        out = hd([x.to(DEV) for x in g["x"]])
+    y, maps = out["one2one"]
+    for a, b in zip(maps, g["maps"]):
+        check(a, b, 1e-3, "eval map")
+    check(y, g["y"], 1e-3, "decoded")
+    # the module must not stay mutated (the reference leaves padding=0 behind)
+    assert hd.o2o_heads[1][0][0].conv.padding == (k1 // 2, k1 // 2)
+
+
+def _tiny_cfg(name, **over):
+    d = y3d.yaml_model_load(name)
+    d.update(over)
+    return d
+
+
+TINY = dict(scales={"n": [0.33, 0.125, 1024]}, scale="n",
+            channels={k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")})
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 8e-2)])
+@pytest.mark.parametrize("tag,over", [("e2e_tiny3d_s", dict(kernel_size_1=3, kernel_size_2=3, num_scales=3)),
+                                      ("e2e_tiny3d_m", dict(kernel_size_1=3, kernel_size_2=1, num_scales=2))])
+def test_e2e_tiny3d_vs_reference_golden(tag, over, dtype, tol):
+    y3d.set_compute_dtype(dtype)
+    g = load_golden(tag)
+    cfg = _tiny_cfg("yolov10s_3D.yaml" if tag.endswith("_s") else "yolov10m_3D.yaml", **TINY, **over)
+    model = y3d.YOLOv10_3DDetectionModel(cfg)
+    n_ok, n_all = model.load(g["state"])
+    assert n_ok == len(g["state"])
+    model = model.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in g["batch"].items()}
+    batch["img"] = g["img"].to(DEV)
+    loss, items = model(batch)
+    check(items, g["items"], tol, "loss items")
+    check(loss.reshape(()), g["loss"].reshape(()), tol, "loss")
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k, gv in g["grads"].items():
+        check(named[k].grad, gv, tol * 5, f"grad {k}")
+    if dtype == torch.float32:
+        sd = model.state_dict()
+        for k, v in g["state_after"].items():
+            check(sd[k].float(), v.float(), 1e-3, f"state {k}")
+        # eval + postprocess on the state the fixture's eval pass saw
+        model.load({**g["state"], **g["state_after"]})
+        model.eval()
+        with torch.no_grad():
+            y = model(g["img_eval"].to(DEV))["one2one"][0]
+        check(y, g["y_eval"], 2e-3, "eval y")
+        from yolov10_3d_amd.loss import v10_3Dpostprocess
+        reg, sc, lab = v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
+        assert torch.equal(lab.cpu(), g["post_labels"].long())
+        check(sc, g["post_scores"], 2e-3, "post scores")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 8e-2)])
+def test_e2e_tiny2d_vs_reference_golden(dtype, tol):
+    y3d.set_compute_dtype(dtype)
+    g = load_golden("e2e_tiny2d")
+    cfg = _tiny_cfg("yolov10n.yaml", nc=20, scales={"n": [0.33, 0.125, 1024]}, scale="n")
+    model = y3d.YOLOv10DetectionModel(cfg)
+    n_ok, _ = model.load(g["state"])
+    assert n_ok == len(g["state"])
+    model = model.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in g["batch"].items()}
+    batch["img"] = g["img"].to(DEV)
+    loss, items = model(batch)
+    check(items, g["items"], tol, "loss items")
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k, gv in g["grads"].items():
+        check(named[k].grad, gv, tol * 5, f"grad {k}")
+    if dtype == torch.float32:
+        model.load({**g["state"], **g["state_after"]})
+        model.eval()
+        with torch.no_grad():
+            out = model(g["img"].to(DEV))
+        check(out["one2one"][0], g["y_eval_o2o"], 2e-3, "eval o2o")
+        check(out["one2many"][0], g["y_eval_o2m"], 2e-3, "eval o2m")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fresh seeded inputs at realistic channel counts: HIP vs the CPU oracle restatement (fp32 mode)
+# ---------------------------------------------------------------------------------------------------------
+CASES = [
+    # c1, c2, k, s, g, H, W, B
+    (128, 128, 3, 1, 1, 40, 40, 2),   # the headline K1 shape (smaller map)
+    (256, 128, 3, 1, 1, 20, 20, 2),
+    (64, 64, 3, 1, 1, 33, 29, 3),     # ragged spatial dims, BC=64 tile
+    (32, 32, 3, 1, 1, 17, 23, 2),     # BC=32 tile
+    (64, 128, 3, 2, 1, 40, 40, 2),    # stride-2 dense (dgrad gather with stride)
+    (384, 128, 1, 1, 1, 20, 20, 2),   # 1x1 GEMM
+    (48, 96, 3, 2, 1, 30, 30, 2),     # M-model channel counts (multiples of 16, not 64)
+    (256, 256, 3, 1, 2, 16, 16, 2),   # grouped (the fused-head second layer shape family)
+    (256, 256, 3, 2, 256, 20, 20, 2),  # depth-wise s2 (SCDown)
+    (128, 128, 7, 1, 128, 20, 20, 2),  # depth-wise 7x7 (RepVGGDW)
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bn_silu_vs_oracle(case, dtype, tol):
+    c1, c2, k, s, g, H, W, B = case
+    y3d.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    mod = M.Conv(c1, c2, k, s, None, g)
+    with torch.no_grad():
+        mod.bn.weight.uniform_(0.8, 1.2)
+        mod.bn.bias.uniform_(-0.2, 0.2)
+    mod.bn.eps, mod.bn.momentum = 1e-3, 0.03
+    st = {"model.0." + kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(B, c1, H, W)
+    # oracle (CPU)
+    for kk, v in st.items():
+        if v.is_floating_point() and "running" not in kk:
+            v.requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = RS.conv_bn_act(RS.Ctx(st, True), "model.0", xo, k, s, g)
+    r = torch.randn_like(yo)
+    (yo * r).sum().backward()
+    # HIP
+    mod = mod.to(DEV).train()
+    xh = x.to(DEV).requires_grad_(True)
+    yh = mod(xh)
+    check(yh, yo, tol, "y")
+    (yh.float() * r.to(DEV)).sum().backward()
+    check(xh.grad, xo.grad, tol * 3, "dx")
+    check(mod.conv.weight.grad, st["model.0.conv.weight"].grad, tol * 3, "dW")
+    check(mod.bn.weight.grad, st["model.0.bn.weight"].grad, tol * 3, "dgamma")
+    check(mod.bn.bias.grad, st["model.0.bn.bias"].grad, tol * 3, "dbeta")
+    check(mod.bn.running_var, st["model.0.bn.running_var"], 1e-3 if dtype == torch.float32 else 2e-2, "running_var")
+
+
+def test_conv_on_channel_slice_views():
+    """chunk()/split() views feed the kernels without copies (C2f, PSA)"""
+    y3d.set_compute_dtype(torch.float32)
+    torch.manual_seed(1)
+    mod = M.Conv(32, 32, 3, 1)
+    mod.bn.eps, mod.bn.momentum = 1e-3, 0.03
+    st = {"model.0." + kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(2, 64, 12, 12)
+    yo = RS.conv_bn_act(RS.Ctx(st, True), "model.0", x[:, 32:], 3)
+    big = y3d.ops.to_nhwc(x.to(DEV), torch.float32)
+    yh = mod.to(DEV).train()(big[:, 32:])
+    check(yh, yo, 1e-3, "slice conv")
+
+
+def test_hip_library_is_the_path():
+    """no silent fallback: CPU tensors must be refused"""
+    y3d.set_compute_dtype(torch.float32)
+    mod = M.Conv(16, 16, 3)
+    with pytest.raises(y3d.Y3DError):
+        mod(torch.randn(1, 16, 8, 8))

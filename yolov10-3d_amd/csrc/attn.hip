@@ -1,0 +1,243 @@
+// PSA attention core (reference nn/modules/block.py:785-797): per (image, head)
+//   attn = softmax_j( scale * q_i . k_j ),  out_i = sum_j attn_ij v_j
+// on the NHWC qkv tensor whose per-head channel block is [q(kd) | k(kd) | v(hd)].
+// Flash-style single pass (online softmax, no N x N matrix in memory), fp32 math, one query (or key)
+// per lane with the other operand streamed through LDS in 64-row tiles.  N is tiny on this path
+// (400 @640^2, 1600 @1280^2; 0.1 % of the step's FLOPs), so round 1 keeps it on the VALU; the MFMA
+// QK^T variant is listed in DESIGN.md as the next step for this kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int TK = 64;
+
+struct AttnP {
+  const void* qkv;   // [B][N][nh*(2kd+hd)]
+  long qsw;          // pixel stride of qkv
+  void* out;         // [B][N][nh*hd]
+  long osw;
+  float* lse;        // [B][nh][N]
+  int B, N, nh, kd, hd;
+  float scale;
+};
+
+template <typename T, int KD, int HD>
+__global__ __launch_bounds__(128) void attn_fwd_kernel(AttnP p) {
+  __shared__ float sK[TK][KD];
+  __shared__ float sV[TK][HD];
+  const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  const int hoff = h * (2 * KD + HD);
+  const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
+  float q[KD], o[HD];
+  const bool valid = i < p.N;
+#pragma unroll
+  for (int d = 0; d < KD; ++d) q[d] = valid ? TT<T>::ld(base + (long)i * p.qsw + d) * p.scale : 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  for (int j0 = 0; j0 < p.N; j0 += TK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < TK * KD; e += 128) {
+      int r = e / KD, d = e % KD;
+      sK[r][d] = (j0 + r < p.N) ? TT<T>::ld(base + (long)(j0 + r) * p.qsw + KD + d) : 0.f;
+    }
+    for (int e = threadIdx.x; e < TK * HD; e += 128) {
+      int r = e / HD, d = e % HD;
+      sV[r][d] = (j0 + r < p.N) ? TT<T>::ld(base + (long)(j0 + r) * p.qsw + 2 * KD + d) : 0.f;
+    }
+    __syncthreads();
+    const int jn = min(TK, p.N - j0);
+    for (int j = 0; j < jn; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < KD; ++d) s += q[d] * sK[j][d];
+      if (s > m) {
+        float corr = __expf(m - s);
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] *= corr;
+        m = s;
+      }
+      float pj = __expf(s - m);
+      l += pj;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] += pj * sV[j][d];
+    }
+  }
+  if (valid) {
+    float inv = 1.f / l;
+    T* dst = (T*)p.out + ((long)b * p.N + i) * p.osw + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) TT<T>::st(dst + d, o[d] * inv);
+    p.lse[((long)b * p.nh + h) * p.N + i] = m + __logf(l);
+  }
+}
+
+struct AttnBP {
+  const void* qkv; long qsw;
+  const void* out; long osw;     // forward output (for delta)
+  const void* dout; long dsw;    // grad wrt out, [B][N][nh*hd]
+  const void* dv_extra; long esw;  // optional extra grad for v (from the `pe` branch), [B][N][nh*hd]
+  void* dqkv; long gsw;          // [B][N][nh*(2kd+hd)]
+  const float* lse;
+  float* delta;                  // [B][nh][N]
+  int B, N, nh, kd, hd;
+  float scale;
+};
+
+// dq_i = scale * sum_j ds_ij k_j,   ds_ij = p_ij (do_i . v_j - delta_i)
+template <typename T, int KD, int HD>
+__global__ __launch_bounds__(128) void attn_bwd_q_kernel(AttnBP p) {
+  __shared__ float sK[TK][KD];
+  __shared__ float sV[TK][HD];
+  const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  const int hoff = h * (2 * KD + HD);
+  const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
+  const bool valid = i < p.N;
+  float q[KD], dq[KD], dO[HD];
+  float delta = 0.f, lse = 0.f;
+#pragma unroll
+  for (int d = 0; d < KD; ++d) { q[d] = valid ? TT<T>::ld(base + (long)i * p.qsw + d) * p.scale : 0.f; dq[d] = 0.f; }
+  if (valid) {
+    const T* op = (const T*)p.out + ((long)b * p.N + i) * p.osw + h * HD;
+    const T* dp = (const T*)p.dout + ((long)b * p.N + i) * p.dsw + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dO[d] = TT<T>::ld(dp + d); delta += dO[d] * TT<T>::ld(op + d); }
+    lse = p.lse[((long)b * p.nh + h) * p.N + i];
+    p.delta[((long)b * p.nh + h) * p.N + i] = delta;
+  } else {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dO[d] = 0.f;
+  }
+  for (int j0 = 0; j0 < p.N; j0 += TK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < TK * KD; e += 128) {
+      int r = e / KD, d = e % KD;
+      sK[r][d] = (j0 + r < p.N) ? TT<T>::ld(base + (long)(j0 + r) * p.qsw + KD + d) : 0.f;
+    }
+    for (int e = threadIdx.x; e < TK * HD; e += 128) {
+      int r = e / HD, d = e % HD;
+      sV[r][d] = (j0 + r < p.N) ? TT<T>::ld(base + (long)(j0 + r) * p.qsw + 2 * KD + d) : 0.f;
+    }
+    __syncthreads();
+    const int jn = min(TK, p.N - j0);
+    for (int j = 0; j < jn; ++j) {
+      float s = 0.f, dpv = 0.f;
+#pragma unroll
+      for (int d = 0; d < KD; ++d) s += q[d] * sK[j][d];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dpv += dO[d] * sV[j][d];
+      float ds = __expf(s - lse) * (dpv - delta);
+#pragma unroll
+      for (int d = 0; d < KD; ++d) dq[d] += ds * sK[j][d];
+    }
+  }
+  if (valid) {
+    T* dst = (T*)p.dqkv + ((long)b * p.N + i) * p.gsw + hoff;
+#pragma unroll
+    for (int d = 0; d < KD; ++d) TT<T>::st(dst + d, dq[d] * p.scale);
+  }
+}
+
+// dk_j = scale * sum_i ds_ij q_i ;  dv_j = sum_i p_ij do_i (+ dv_extra_j)
+template <typename T, int KD, int HD>
+__global__ __launch_bounds__(128) void attn_bwd_kv_kernel(AttnBP p) {
+  __shared__ float sQ[TK][KD];
+  __shared__ float sD[TK][HD];
+  __shared__ float sL[TK], sDel[TK];
+  const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  const int hoff = h * (2 * KD + HD);
+  const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
+  const bool valid = j < p.N;
+  float k[KD], v[HD], dk[KD], dv[HD];
+#pragma unroll
+  for (int d = 0; d < KD; ++d) { k[d] = valid ? TT<T>::ld(base + (long)j * p.qsw + KD + d) : 0.f; dk[d] = 0.f; }
+#pragma unroll
+  for (int d = 0; d < HD; ++d) { v[d] = valid ? TT<T>::ld(base + (long)j * p.qsw + 2 * KD + d) : 0.f; dv[d] = 0.f; }
+  for (int i0 = 0; i0 < p.N; i0 += TK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < TK * KD; e += 128) {
+      int r = e / KD, d = e % KD;
+      sQ[r][d] = (i0 + r < p.N) ? TT<T>::ld(base + (long)(i0 + r) * p.qsw + d) * p.scale : 0.f;
+    }
+    for (int e = threadIdx.x; e < TK * HD; e += 128) {
+      int r = e / HD, d = e % HD;
+      sD[r][d] = (i0 + r < p.N) ? TT<T>::ld((const T*)p.dout + ((long)b * p.N + i0 + r) * p.dsw + h * HD + d) : 0.f;
+    }
+    if (threadIdx.x < TK) {
+      int i = i0 + threadIdx.x;
+      sL[threadIdx.x] = i < p.N ? p.lse[((long)b * p.nh + h) * p.N + i] : 0.f;
+      sDel[threadIdx.x] = i < p.N ? p.delta[((long)b * p.nh + h) * p.N + i] : 0.f;
+    }
+    __syncthreads();
+    const int in = min(TK, p.N - i0);
+    for (int i = 0; i < in; ++i) {
+      float s = 0.f, dpv = 0.f;
+#pragma unroll
+      for (int d = 0; d < KD; ++d) s += sQ[i][d] * k[d];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dpv += sD[i][d] * v[d];
+      float pij = __expf(s - sL[i]);
+      float ds = pij * (dpv - sDel[i]);
+#pragma unroll
+      for (int d = 0; d < KD; ++d) dk[d] += ds * sQ[i][d];   // sQ already carries `scale`
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dv[d] += pij * sD[i][d];
+    }
+  }
+  if (valid) {
+    T* dst = (T*)p.dqkv + ((long)b * p.N + j) * p.gsw + hoff;
+#pragma unroll
+    for (int d = 0; d < KD; ++d) TT<T>::st(dst + KD + d, dk[d]);
+    const T* ex = p.dv_extra ? (const T*)p.dv_extra + ((long)b * p.N + j) * p.esw + h * HD : nullptr;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) TT<T>::st(dst + 2 * KD + d, dv[d] + (ex ? TT<T>::ld(ex + d) : 0.f));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_attn_fwd(int dtype, const void* qkv, int64_t qsw, void* out, int64_t osw, float* lse, int B, int N, int nh, int kd, int hd,
+                 float scale, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "attn_fwd: bad dtype");
+  Y3D_CHECK((kd == 32 && hd == 64) || (kd == 36 && hd == 72), "attn_fwd: unsupported head dims kd=%d hd=%d (32/64 and 36/72 built)", kd, hd);
+  AttnP p{qkv, (long)qsw, out, (long)osw, lse, B, N, nh, kd, hd, scale};
+  dim3 grid(cdiv(N, 128), B * nh), block(128);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16) {
+    if (kd == 32) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 32, 64>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 36, 72>), grid, block, 0, st, p);
+  } else {
+    if (kd == 32) hipLaunchKernelGGL((attn_fwd_kernel<float, 32, 64>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<float, 36, 72>), grid, block, 0, st, p);
+  }
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64_t osw, const void* dout, int64_t dsw,
+                 const void* dv_extra, int64_t esw, const float* lse, float* delta, void* dqkv, int64_t gsw, int B, int N, int nh,
+                 int kd, int hd, float scale, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "attn_bwd: bad dtype");
+  Y3D_CHECK((kd == 32 && hd == 64) || (kd == 36 && hd == 72), "attn_bwd: unsupported head dims kd=%d hd=%d", kd, hd);
+  AttnBP p{qkv, (long)qsw, out, (long)osw, dout, (long)dsw, dv_extra, (long)esw, dqkv, (long)gsw, lse, delta, B, N, nh, kd, hd, scale};
+  dim3 grid(cdiv(N, 128), B * nh), block(128);
+  hipStream_t st = (hipStream_t)stream;
+#define ATT_BWD(T, KD, HD)                                                              \
+  hipLaunchKernelGGL((attn_bwd_q_kernel<T, KD, HD>), grid, block, 0, st, p);           \
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, KD, HD>), grid, block, 0, st, p)
+  if (dtype == Y3D_BF16) {
+    if (kd == 32) { ATT_BWD(bf16_t, 32, 64); } else { ATT_BWD(bf16_t, 36, 72); }
+  } else {
+    if (kd == 32) { ATT_BWD(float, 32, 64); } else { ATT_BWD(float, 36, 72); }
+  }
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

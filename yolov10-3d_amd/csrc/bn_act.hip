@@ -1,0 +1,361 @@
+// BatchNorm (training statistics or running statistics) + SiLU + residual, NHWC, HBM-bound.
+// Reference semantics: nn/modules/conv.py:120-122 (act(bn(conv(x)))), BN eps/momentum from
+// utils/torch_utils.py:327-337, residual adds block.py:342,758,816-817, RepVGGDW block.py:711.
+//
+//   u = y*scale[c] + shift[c] (+ res if RES_PRE);  z = act(u) (+ res if RES_POST)
+//
+// Every thread owns one 16-byte channel chunk of one pixel; per-channel reductions are two-level
+// (per-block partial slabs, then a finalize kernel) so results are bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+// partial[nblk][C][2] (sum, sumsq) -> mean/invstd/scale/shift (+ running stats update)
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  __shared__ double sh[4][64][2];
+  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cx;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int b = ry; b < nblk; b += 4) {
+      s += (double)part[((long)b * C + c) * 2];
+      q += (double)part[((long)b * C + c) * 2 + 1];
+    }
+  sh[ry][cx][0] = s;
+  sh[ry][cx][1] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    for (int r = 1; r < 4; ++r) { s += sh[r][cx][0]; q += sh[r][cx][1]; }
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[c] * invstd;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = sc;
+    shift_out[c] = beta[c] - (float)mean * sc;
+    if (run_mean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// eval: scale/shift from the running statistics
+__global__ void bn_eval_scale_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ run_mean, const float* __restrict__ run_var, float eps,
+                                     float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sc = gamma[c] / sqrtf(run_var[c] + eps);
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - run_mean[c] * sc;
+}
+
+template <typename T, int ACT, int RES>  // RES: 0 none, 1 post-activation, 2 pre-activation
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, long ysw, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const T* __restrict__ res, long rsw, T* __restrict__ z, long zsw, long P, int C) {
+  constexpr int CE = TT<T>::CE;
+  const int cpr = C / CE;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = P * cpr;
+  for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long px = idx / cpr;
+    int c = (int)(idx - px * cpr) * CE;
+    float v[CE], r[CE];
+    Chunk<T>::unpack(*(const uint4*)(y + px * ysw + c), v);
+    if (RES) Chunk<T>::unpack(*(const uint4*)(res + px * rsw + c), r);
+#pragma unroll
+    for (int j = 0; j < CE; ++j) {
+      float u = v[j] * scale[c + j] + shift[c + j];
+      if (RES == 2) u += r[j];
+      if (ACT) u = silu_f(u);
+      if (RES == 1) u += r[j];
+      v[j] = u;
+    }
+    *(uint4*)(z + px * zsw + c) = Chunk<T>::pack(v);
+  }
+}
+
+// backward pass 1: g = dz * act'(u); per-block partial sums of g and g*xhat.
+// Block = 256 threads = (64/CE... ) organised as CT chunk-threads x PT pixel-threads over a 64-channel slab.
+template <typename T, int ACT, int RES>
+__global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
+                                         const T* __restrict__ res, long rsw, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const float* __restrict__ mean,
+                                         const float* __restrict__ invstd, float* __restrict__ part, long P, int C, int px_per_block) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int CT = 64 / CE;    // chunk-threads per 64-channel slab
+  constexpr int PT = 256 / CT;   // pixel-threads
+  __shared__ float sh[PT][64][2];
+  const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+  const int c = blockIdx.y * 64 + ct * CE;
+  float s1[CE], s2[CE];
+#pragma unroll
+  for (int j = 0; j < CE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (c < C) {
+    float sc[CE], sf[CE], mu[CE], is[CE];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) { sc[j] = scale[c + j]; sf[j] = shift[c + j]; mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+    long pbeg = (long)blockIdx.x * px_per_block;
+    long pend = pbeg + px_per_block < P ? pbeg + px_per_block : P;
+    for (long px = pbeg + pt; px < pend; px += PT) {
+      float v[CE], d[CE], r[CE];
+      Chunk<T>::unpack(*(const uint4*)(y + px * ysw + c), v);
+      Chunk<T>::unpack(*(const uint4*)(dz + px * dsw + c), d);
+      if (RES == 2) Chunk<T>::unpack(*(const uint4*)(res + px * rsw + c), r);
+#pragma unroll
+      for (int j = 0; j < CE; ++j) {
+        float g = d[j];
+        if (ACT) {
+          float u = v[j] * sc[j] + sf[j];
+          if (RES == 2) u += r[j];
+          g *= silu_grad_f(u);
+        }
+        s1[j] += g;
+        s2[j] += g * (v[j] - mu[j]) * is[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CE; ++j) { sh[pt][ct * CE + j][0] = s1[j]; sh[pt][ct * CE + j][1] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    int cc = blockIdx.y * 64 + threadIdx.x;
+    if (cc < C) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < PT; ++r) { a += sh[r][threadIdx.x][0]; b += sh[r][threadIdx.x][1]; }
+      part[((long)blockIdx.x * C + cc) * 2] = a;
+      part[((long)blockIdx.x * C + cc) * 2 + 1] = b;
+    }
+  }
+}
+
+// partial[nblk][C][2] -> dgamma (sum g*xhat), dbeta (sum g), and the two per-channel means used by pass 2
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate, float* __restrict__ mg, float* __restrict__ mgx) {
+  __shared__ double sh[4][64][2];
+  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cx;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int b = ry; b < nblk; b += 4) {
+      s += (double)part[((long)b * C + c) * 2];
+      q += (double)part[((long)b * C + c) * 2 + 1];
+    }
+  sh[ry][cx][0] = s;
+  sh[ry][cx][1] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    for (int r = 1; r < 4; ++r) { s += sh[r][cx][0]; q += sh[r][cx][1]; }
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+    mg[c] = (float)(s / count);
+    mgx[c] = (float)(q / count);
+  }
+}
+
+// backward pass 2: dy = scale * (g - mean(g) - xhat * mean(g*xhat))      [TRAIN]
+//                  dy = scale * g                                         [eval / frozen stats]
+// optionally also emits g itself (gradient of a pre-activation residual).
+template <typename T, int ACT, int RES, bool TRAIN>
+__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
+                                        const T* __restrict__ res, long rsw, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd, const float* __restrict__ mg,
+                                        const float* __restrict__ mgx, T* __restrict__ dy, long dysw, T* __restrict__ dres,
+                                        long drsw, long P, int C) {
+  constexpr int CE = TT<T>::CE;
+  const int cpr = C / CE;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = P * cpr;
+  for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long px = idx / cpr;
+    int c = (int)(idx - px * cpr) * CE;
+    float v[CE], d[CE], r[CE], o[CE];
+    Chunk<T>::unpack(*(const uint4*)(y + px * ysw + c), v);
+    Chunk<T>::unpack(*(const uint4*)(dz + px * dsw + c), d);
+    if (RES == 2) Chunk<T>::unpack(*(const uint4*)(res + px * rsw + c), r);
+#pragma unroll
+    for (int j = 0; j < CE; ++j) {
+      float g = d[j];
+      if (ACT) {
+        float u = v[j] * scale[c + j] + shift[c + j];
+        if (RES == 2) u += r[j];
+        g *= silu_grad_f(u);
+      }
+      d[j] = g;
+      if (TRAIN) {
+        float xh = (v[j] - mean[c + j]) * invstd[c + j];
+        o[j] = scale[c + j] * (g - mg[c + j] - xh * mgx[c + j]);
+      } else {
+        o[j] = scale[c + j] * g;
+      }
+    }
+    *(uint4*)(dy + px * dysw + c) = Chunk<T>::pack(o);
+    if (RES == 2 && dres) *(uint4*)(dres + px * drsw + c) = Chunk<T>::pack(d);
+  }
+}
+
+// column sums of a [P][C] tensor into partial[nblk][C][2] (second slot zero) — bias gradients
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long xsw, float* __restrict__ part, long P, int C, int px_per_block) {
+  __shared__ float sh[4][64];
+  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  int c = blockIdx.y * 64 + cx;
+  float s = 0.f;
+  long pbeg = (long)blockIdx.x * px_per_block;
+  long pend = pbeg + px_per_block < P ? pbeg + px_per_block : P;
+  if (c < C)
+    for (long px = pbeg + ry; px < pend; px += 4) s += TT<T>::ld(x + px * xsw + c);
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s += sh[1][cx] + sh[2][cx] + sh[3][cx];
+    part[((long)blockIdx.x * C + c) * 2] = s;
+    part[((long)blockIdx.x * C + c) * 2 + 1] = 0.f;
+  }
+}
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+template <typename T, int ACT>
+int launch_fwd(int res_mode, const void* y, long ysw, const float* scale, const float* shift, const void* res, long rsw,
+               void* z, long zsw, long P, int C, hipStream_t st) {
+  dim3 g(ew_grid(P * (C / TT<T>::CE))), b(256);
+  if (res_mode == 0) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 0>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C);
+  else if (res_mode == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 1>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C);
+  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 2>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_bn_finalize(const float* partials, int nblk, int C, int64_t count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                    float* shift, void* stream) {
+  Y3D_CHECK(nblk > 0 && C > 0 && count > 0, "bn_finalize: empty");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, (double)count,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_bn_eval_scale(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, running_mean,
+                     running_var, eps, scale, shift);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+static int ew_check(const char* what, int dtype, const void* a, int64_t asw, int C) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "%s: bad dtype", what);
+  Y3D_CHECK(C % ce == 0, "%s: C=%d not a multiple of %d", what, C, ce);
+  Y3D_CHECK(a == nullptr || ((((uintptr_t)a) & 15) == 0 && asw % ce == 0), "%s: tensor not 16-byte aligned", what);
+  return Y3D_OK;
+}
+
+int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, const float* shift, int act, int res_mode,
+                   const void* res, int64_t rsw, void* z, int64_t zsw, int64_t P, int C, void* stream) {
+  if (ew_check("bn_act_fwd y", dtype, y, ysw, C) || ew_check("bn_act_fwd z", dtype, z, zsw, C) ||
+      ew_check("bn_act_fwd res", dtype, res, rsw, C)) return Y3D_ERR_INVALID;
+  Y3D_CHECK(res_mode == 0 || res != nullptr, "bn_act_fwd: residual missing");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16) return act ? launch_fwd<bf16_t, 1>(res_mode, y, ysw, scale, shift, res, rsw, z, zsw, P, C, st)
+                                    : launch_fwd<bf16_t, 0>(res_mode, y, ysw, scale, shift, res, rsw, z, zsw, P, C, st);
+  return act ? launch_fwd<float, 1>(res_mode, y, ysw, scale, shift, res, rsw, z, zsw, P, C, st)
+             : launch_fwd<float, 0>(res_mode, y, ysw, scale, shift, res, rsw, z, zsw, P, C, st);
+}
+
+int y3d_bn_bwd_blocks(int64_t P) {
+  long n = (P + 511) / 512;
+  return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+}
+
+#define BWD_REDUCE(T, A, R)                                                                                                  \
+  hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, A, R>), grid, dim3(256), 0, st, (const T*)y, ysw, (const T*)dz, dsw,        \
+                     (const T*)res, rsw, scale, shift, mean, invstd, partials, (long)P, C, ppb)
+
+int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,
+                          const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                          int res_mode, float* partials, int64_t P, int C, void* stream) {
+  if (ew_check("bn_act_bwd_reduce y", dtype, y, ysw, C) || ew_check("bn_act_bwd_reduce dz", dtype, dz, dsw, C) ||
+      ew_check("bn_act_bwd_reduce res", dtype, res, rsw, C)) return Y3D_ERR_INVALID;
+  int nblk = y3d_bn_bwd_blocks(P);
+  int ppb = (int)((P + nblk - 1) / nblk);
+  dim3 grid(nblk, cdiv(C, 64));
+  hipStream_t st = (hipStream_t)stream;
+  int r2 = (res_mode == 2 && act) ? 2 : 0;
+  if (dtype == Y3D_BF16) {
+    if (act) { if (r2) BWD_REDUCE(bf16_t, 1, 2); else BWD_REDUCE(bf16_t, 1, 0); }
+    else BWD_REDUCE(bf16_t, 0, 0);
+  } else {
+    if (act) { if (r2) BWD_REDUCE(float, 1, 2); else BWD_REDUCE(float, 1, 0); }
+    else BWD_REDUCE(float, 0, 0);
+  }
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_bn_bwd_finalize(const float* partials, int nblk, int C, int64_t count, float* dgamma, float* dbeta, int accumulate,
+                        float* mean_g, float* mean_gx, void* stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
+                     (double)count, dgamma, dbeta, accumulate, mean_g, mean_gx);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+#define BWD_APPLY(T, A, R, TR)                                                                                               \
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, A, R, TR>), grid, dim3(256), 0, st, (const T*)y, ysw, (const T*)dz, dsw,    \
+                     (const T*)res, rsw, scale, shift, mean, invstd, mean_g, mean_gx, (T*)dy, dysw, (T*)dres, drsw, (long)P, C)
+#define BWD_APPLY_T(T)                                                        \
+  do {                                                                        \
+    if (train) {                                                              \
+      if (act) { if (r2) BWD_APPLY(T, 1, 2, true); else BWD_APPLY(T, 1, 0, true); } \
+      else { if (r2) BWD_APPLY(T, 0, 2, true); else BWD_APPLY(T, 0, 0, true); }     \
+    } else {                                                                  \
+      if (act) { if (r2) BWD_APPLY(T, 1, 2, false); else BWD_APPLY(T, 1, 0, false); } \
+      else { if (r2) BWD_APPLY(T, 0, 2, false); else BWD_APPLY(T, 0, 0, false); }     \
+    }                                                                         \
+  } while (0)
+
+int y3d_bn_act_bwd_apply(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,
+                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* mean_g, const float* mean_gx, int act, int res_mode, int train, void* dy, int64_t dysw,
+                         void* dres, int64_t drsw, int64_t P, int C, void* stream) {
+  if (ew_check("bn_act_bwd_apply y", dtype, y, ysw, C) || ew_check("bn_act_bwd_apply dz", dtype, dz, dsw, C) ||
+      ew_check("bn_act_bwd_apply dy", dtype, dy, dysw, C) || ew_check("bn_act_bwd_apply res", dtype, res, rsw, C) ||
+      ew_check("bn_act_bwd_apply dres", dtype, dres, drsw, C)) return Y3D_ERR_INVALID;
+  int r2 = res_mode == 2 ? 2 : 0;
+  dim3 grid(ew_grid(P * (C / (dtype == Y3D_BF16 ? 8 : 4))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16) BWD_APPLY_T(bf16_t); else BWD_APPLY_T(float);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_colsum_partials(int dtype, const void* x, int64_t xsw, float* partials, int64_t P, int C, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "colsum: bad dtype");
+  int nblk = y3d_bn_bwd_blocks(P);
+  int ppb = (int)((P + nblk - 1) / nblk);
+  dim3 grid(nblk, cdiv(C, 64));
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)xsw, partials, (long)P, C, ppb);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)xsw, partials, (long)P, C, ppb);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,637 @@
+// Dense / grouped convolution as an im2col-free implicit GEMM on the CDNA4 matrix cores.
+//
+//   forward : y[p][co]   = sum_{tap,ci} x[gather(p,tap)][ci] * w[co][tap][ci]      (reference: nn/modules/conv.py:120-122,
+//   dgrad   : dx[p][ci]  = sum_{tap,co} dy[gatherT(p,tap)][co] * w[co][tap][ci]      F.conv2d and its autograd backward)
+//   wgrad   : dw[co][tap][ci] = sum_p dy[p][co] * x[gather(p,tap)][ci]
+//
+// Layout: activations NHWC (channels contiguous) so that for one filter tap a GEMM-K run is a
+// contiguous channel vector; weights are pre-packed K-contiguous per output channel.  Tiles are
+// staged global -> registers -> LDS (16-byte chunks, XOR-swizzled 128-byte rows, halo/zero padding
+// resolved in the loader) and double buffered with one barrier per K step.  MFMA: 16x16x32 bf16
+// (or the exact-f32 16x16x4 form for the fp32 parity mode); the weight tile is the MFMA A operand
+// and the pixel tile the B operand, so each lane ends up with 4 consecutive output channels of one
+// pixel (one 8/16-byte store).  The epilogue optionally emits per-block BatchNorm partial sums
+// (sum, sum of squares per channel), which makes the BN statistics bitwise reproducible (no atomics).
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+  const void* x;   // gathered tensor (fwd: input, dgrad: dy)
+  const void* w;   // packed weights [G][Cn][Kpad]
+  const float* bias;
+  void* y;         // output tensor, pixel-dense
+  float* part;     // optional BN partials [gridDim.x][G*Cn][2]
+  long xsb, xsh, xsw;
+  long ysw;
+  int B, Hg, Wg;   // spatial dims of the gathered tensor
+  int Hq, Wq;      // spatial dims of the output tensor
+  int Cg, Cn, G;   // per-group channels: gathered (GEMM K side), output (GEMM N side)
+  int kh, kw, stride, pad;
+  int Ktot, Kpad;  // taps*Cg and its padding to a chunk multiple (row pitch of packed weights)
+  int M;           // B*Hq*Wq
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  // one K sub-step = 32 elements = 4 chunks; lane reads chunk (ks*4 + lane>>4) of row (lane&15)
+  static constexpr int KSUB = 2;
+  typedef bf16x8_t type;
+  __device__ static __forceinline__ type load(const char* tile, int row, int ks, int lane) {
+    int r = row + (lane & 15);
+    int c = ks * 4 + (lane >> 4);
+    const uint4* p = (const uint4*)(tile + r * 128 + ((c ^ (r & 7)) << 4));
+    return __builtin_bit_cast(bf16x8_t, *p);
+  }
+  __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  // one K sub-step = 4 elements = 1 chunk; lane reads element (lane>>4) of chunk ks of row (lane&15)
+  static constexpr int KSUB = 8;
+  typedef float type;
+  __device__ static __forceinline__ type load(const char* tile, int row, int ks, int lane) {
+    int r = row + (lane & 15);
+    return *(const float*)(tile + r * 128 + ((ks ^ (r & 7)) << 4) + ((lane >> 4) << 2));
+  }
+  __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// BP x BC output tile (pixels x channels), 256 threads = WP x WC waves.
+template <typename T, int BP, int BC, int WP, int WC, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int BKE = TT<T>::BKE;
+  constexpr int RA = BP / 32;  // pixel rows per thread in the loader
+  constexpr int RB = BC / 32;
+  constexpr int TP = BP / WP / 16;
+  constexpr int TC = BC / WC / 16;
+  static_assert(WP * WC == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                      // [2][BP][128B]  pixel tile
+  char* sB = smem + 2 * BP * 128;       // [2][BC][128B]  weight tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wp = wave / WC, wc = wave % WC;
+  const int g = blockIdx.z;
+  const int p0 = blockIdx.x * BP;
+  const int c0 = blockIdx.y * BC;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ Wt = (const T*)p.w;
+
+  // ---- loader state: this thread owns chunk column cc of rows (tid>>3) + 32*i -------------------
+  const int cc = tid & 7;
+  const int r0 = tid >> 3;
+  long abase[RA];
+  int ah[RA], aw[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = p0 + r0 + 32 * i;
+    if (m < p.M) {
+      int b = m / (p.Hq * p.Wq);
+      int rem = m - b * (p.Hq * p.Wq);
+      int hq = rem / p.Wq;
+      int wq = rem - hq * p.Wq;
+      abase[i] = (long)b * p.xsb + (long)g * p.Cg;
+      if (DGRAD) { ah[i] = hq + p.pad; aw[i] = wq + p.pad; }
+      else { ah[i] = hq * p.stride - p.pad; aw[i] = wq * p.stride - p.pad; }
+    } else {
+      abase[i] = -1; ah[i] = 0; aw[i] = 0;
+    }
+  }
+  // K position of this thread's chunk: k = kt*BKE + cc*CE -> (tap r,q ; channel ci)
+  int kpos = cc * CE;
+  int kci = kpos % p.Cg;
+  int ktap = kpos / p.Cg;
+  int kr = ktap / p.kw, kq = ktap - kr * p.kw;
+
+  const int nk = (p.Ktot + BKE - 1) / BKE;
+  uint4 ra[RA], rb[RB];
+
+  auto gload = [&](int kt) {
+    const bool kvalid = kpos < p.Ktot;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kvalid && abase[i] >= 0) {
+        int hh, ww;
+        bool ok;
+        if (DGRAD) {
+          int th = ah[i] - kr, tw = aw[i] - kq;
+          if (p.stride == 1) { hh = th; ww = tw; ok = th >= 0 && tw >= 0; }
+          else {
+            hh = th / p.stride; ww = tw / p.stride;
+            ok = th >= 0 && tw >= 0 && hh * p.stride == th && ww * p.stride == tw;
+          }
+        } else {
+          hh = ah[i] + kr; ww = aw[i] + kq;
+          ok = hh >= 0 && ww >= 0;
+        }
+        if (ok && hh < p.Hg && ww < p.Wg) v = *(const uint4*)(X + abase[i] + (long)hh * p.xsh + (long)ww * p.xsw + kci);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = c0 + r0 + 32 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < p.Cn && kpos < p.Kpad) v = *(const uint4*)(Wt + ((long)(g * p.Cn + n)) * p.Kpad + kpos);
+      rb[i] = v;
+    }
+    // advance to the next K step
+    kpos += BKE;
+    kci += BKE;
+    while (kci >= p.Cg) {
+      kci -= p.Cg;
+      if (++kq == p.kw) { kq = 0; ++kr; }
+    }
+    (void)kt;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int r = r0 + 32 * i;
+      *(uint4*)(sA + buf * BP * 128 + r * 128 + ((cc ^ (r & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int r = r0 + 32 * i;
+      *(uint4*)(sB + buf * BC * 128 + r * 128 + ((cc ^ (r & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4_t acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* tA = sA + cur * BP * 128 + (wp * (BP / WP)) * 128;
+    const char* tB = sB + cur * BC * 128 + (wc * (BC / WC)) * 128;
+#pragma unroll
+    for (int ks = 0; ks < Frag<T>::KSUB; ++ks) {
+      typename Frag<T>::type fb[TP], fa[TC];
+#pragma unroll
+      for (int b = 0; b < TP; ++b) fb[b] = Frag<T>::load(tA, b * 16, ks, lane);
+#pragma unroll
+      for (int a = 0; a < TC; ++a) fa[a] = Frag<T>::load(tB, a * 16, ks, lane);
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = Frag<T>::mma(fa[a], fb[b], acc[a][b]);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------
+  T* __restrict__ Y = (T*)p.y;
+  const int lc = (lane >> 4) * 4;  // channel sub-offset inside a 16x16 tile
+  const int lp = lane & 15;        // pixel sub-offset
+  float ssum[TC][4], ssq[TC][4];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
+
+#pragma unroll
+  for (int a = 0; a < TC; ++a) {
+    const int co = c0 + wc * (BC / WC) + a * 16 + lc;  // first of 4 consecutive channels
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (co + j < p.Cn) bv[j] = p.bias[g * p.Cn + co + j];
+    }
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int m = p0 + wp * (BP / WP) + b * 16 + lp;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = TT<T>::rnd(acc[a][b][j] + bv[j]);
+        ssum[a][j] += v[j];
+        ssq[a][j] += v[j] * v[j];
+      }
+      if (m < p.M) {
+        T* dst = Y + (long)m * p.ysw + (long)g * p.Cn + co;
+        if (co + 3 < p.Cn && ((p.Cn | p.ysw) & 3) == 0) {
+          if (sizeof(T) == 2) {
+            uint2 u;
+            u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *(uint2*)dst = u;
+          } else {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < p.Cn) TT<T>::st(dst + j, v[j]);
+        }
+      }
+    }
+  }
+  if (p.part) {
+    // rows >= M and channels >= Cn contributed exact zeros (zero-filled operands, no bias with stats)
+    float* red = (float*)smem;  // [WP][BC][2], safe: all LDS tile reads finished at the last barrier
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = wave_xor_sum16(ssum[a][j]);
+        float q = wave_xor_sum16(ssq[a][j]);
+        if (lp == 0) {
+          int cl = wc * (BC / WC) + a * 16 + lc + j;
+          red[(wp * BC + cl) * 2 + 0] = s;
+          red[(wp * BC + cl) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < BC && c0 + tid < p.Cn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WP; ++w) { s += red[(w * BC + tid) * 2]; q += red[(w * BC + tid) * 2 + 1]; }
+      float* dst = p.part + ((long)blockIdx.x * (p.G * p.Cn) + g * p.Cn + c0 + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: slab[split][g][co][k] = sum over the split's pixel range of dy[p][co] * x[gather(p, tap(k))][ci(k)]
+// ---------------------------------------------------------------------------------------------------
+struct WgradP {
+  const void* x;
+  const void* dy;
+  float* slab;     // [nsplit][G*Cn][Ktot]
+  long xsb, xsh, xsw;
+  long dsw;        // dy pixel stride (pixel-dense)
+  int B, H, W, Ho, Wo;
+  int Cg, Cn, G;
+  int kh, kw, stride, pad;
+  int Ktot, M, nsplit, chunk_px;  // chunk_px: pixels per split (multiple of BPK)
+};
+
+template <typename T> struct TFrag;
+template <> struct TFrag<bf16_t> {
+  // LDS tile [pixel][128 elements] (256-byte rows); one MFMA k-sub-step = 32 pixels.
+  // A/B fragment: element j of lane l = tile[k0 + 8*(l>>4) + j][i0 + (l&15)] via two transposed 4x16 block reads.
+  typedef bf16x8_t type;
+  static constexpr int KSUB_PX = 32;
+  __device__ static __forceinline__ type load(const char* tile, int i0, int k0, int lane) {
+    int grp = lane >> 4, li = lane & 15;
+    int q = li >> 2, pp = li & 3;
+    const char* a0 = tile + (k0 + 8 * grp + q) * 256 + (i0 + 4 * pp) * 2;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * 256));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+  __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct TFrag<float> {
+  // LDS tile [pixel][128 floats] (512-byte rows); one MFMA k-sub-step = 4 pixels.
+  typedef float type;
+  static constexpr int KSUB_PX = 4;
+  __device__ static __forceinline__ type load(const char* tile, int i0, int k0, int lane) {
+    return *(const float*)(tile + (k0 + (lane >> 4)) * 512 + (i0 + (lane & 15)) * 4);
+  }
+  __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// 128 (co) x 128 (k index) output tile, reduction over pixels in steps of BPK; 4 waves as 2x2 (64x64 each).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int BPK = TT<T>::BKE;            // 64 pixels (bf16) / 32 pixels (fp32) per step: 16 KB per operand tile
+  constexpr int ROWB = 128 * sizeof(T);      // bytes per pixel row
+  constexpr int CPR = ROWB / 16;             // chunks per row (16 / 32)
+  constexpr int NCH = BPK * CPR / 256;       // chunks per thread per operand (4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sD = smem;                 // [2][BPK][ROWB]  dy tile  (pixel x co)
+  char* sX = smem + 2 * BPK * ROWB;  // [2][BPK][ROWB]  x tile   (pixel x k)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int g = blockIdx.z % p.G;
+  const int split = blockIdx.z / p.G;
+  const int j0 = blockIdx.x * 128;  // k-index tile origin
+  const int i0 = blockIdx.y * 128;  // co tile origin
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ D = (const T*)p.dy;
+
+  const int mbeg = split * p.chunk_px;
+  const int mend = min(p.M, mbeg + p.chunk_px);
+  const int nsteps = (mend - mbeg + BPK - 1) / BPK;
+
+  // chunk q = tid + 256*i -> row q / CPR, column chunk q % CPR.  CPR divides 256 so the column is fixed per thread.
+  const int cc = tid % CPR;
+  const int rr0 = tid / CPR;
+  constexpr int RSTEP = 256 / CPR;
+  // x-tile column: k index -> (tap, ci) fixed for the whole kernel
+  const int kx = j0 + cc * CE;
+  const bool kx_ok = kx < p.Ktot;
+  int tap = 0, ci = 0, tr = 0, tq = 0;
+  if (kx_ok) { tap = kx / p.Cg; ci = kx - tap * p.Cg; tr = tap / p.kw; tq = tap - tr * p.kw; }
+  const int cd = i0 + cc * CE;  // dy-tile column: output channel
+  const bool cd_ok = cd < p.Cn;
+  const int HW = p.Ho * p.Wo;
+
+  uint4 rd[NCH], rx[NCH];
+  auto gload = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int m = mbeg + st * BPK + rr0 + RSTEP * i;
+      uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
+      if (m < mend) {
+        if (cd_ok) vd = *(const uint4*)(D + (long)m * p.dsw + (long)g * p.Cn + cd);
+        if (kx_ok) {
+          int b = m / HW;
+          int rem = m - b * HW;
+          int ho = rem / p.Wo;
+          int wo = rem - ho * p.Wo;
+          int hh = ho * p.stride - p.pad + tr, ww = wo * p.stride - p.pad + tq;
+          if (hh >= 0 && ww >= 0 && hh < p.H && ww < p.W)
+            vx = *(const uint4*)(X + (long)b * p.xsb + (long)hh * p.xsh + (long)ww * p.xsw + (long)g * p.Cg + ci);
+        }
+      }
+      rd[i] = vd;
+      rx[i] = vx;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int r = rr0 + RSTEP * i;
+      *(uint4*)(sD + buf * BPK * ROWB + r * ROWB + cc * 16) = rd[i];
+      *(uint4*)(sX + buf * BPK * ROWB + r * ROWB + cc * 16) = rx[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) gload(st + 1);
+    const char* tD = sD + cur * BPK * ROWB;
+    const char* tX = sX + cur * BPK * ROWB;
+#pragma unroll
+    for (int k0 = 0; k0 < BPK; k0 += TFrag<T>::KSUB_PX) {
+      typename TFrag<T>::type fa[4], fb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = TFrag<T>::load(tD, wi * 64 + a * 16, k0, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = TFrag<T>::load(tX, wj * 64 + b * 16, k0, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = TFrag<T>::mma(fa[a], fb[b], acc[a][b]);
+    }
+    if (st + 1 < nsteps) lstore(cur ^ 1);
+    __syncthreads();
+  }
+  // D[i][j]: row i = co = (lane>>4)*4 + reg, col j = k index = lane&15
+  float* slab = p.slab + ((long)split * p.G * p.Cn + (long)g * p.Cn) * p.Ktot;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int k = j0 + wj * 64 + b * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int co = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Cn && k < p.Ktot) slab[(long)co * p.Ktot + k] = acc[a][b][r];
+      }
+    }
+}
+
+// slab[split][co][tap][ci]  ->  grad OIHW [co][ci][tap]  (accumulate optional)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int Ctot,
+                                    int taps, int Cg, int Cg_real, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)Ctot * taps * Cg;
+  if (idx >= n) return;
+  int ci = idx % Cg;
+  int tap = (idx / Cg) % taps;
+  int co = idx / ((long)Cg * taps);
+  if (ci >= Cg_real) return;  // channel padding (stem)
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + idx];
+  long o = ((long)co * Cg_real + ci) * taps + tap;
+  grad[o] = accumulate ? grad[o] + s : s;
+}
+
+// OIHW fp32 -> packed [Cout][taps][Cg_pad] (forward) in T, row pitch Kpad
+template <typename T>
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cg, int Cg_pad, int taps, int Kpad) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)Cout * Kpad;
+  if (idx >= n) return;
+  int k = idx % Kpad;
+  int co = idx / Kpad;
+  float v = 0.f;
+  if (k < taps * Cg_pad) {
+    int tap = k / Cg_pad, ci = k - tap * Cg_pad;
+    if (ci < Cg) v = w[((long)co * Cg + ci) * taps + tap];
+  }
+  TT<T>::st(out + idx, v);
+}
+
+// OIHW fp32 -> packed for dgrad: [G][Cg][taps][Cn] in T (row = input channel, K = (tap, co)), row pitch Kpad
+template <typename T>
+__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int G, int Cn, int Cg, int taps, int Kpad) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)G * Cg * Kpad;
+  if (idx >= n) return;
+  int k = idx % Kpad;
+  int ci = (idx / Kpad) % Cg;
+  int g = idx / ((long)Kpad * Cg);
+  float v = 0.f;
+  if (k < taps * Cn) {
+    int tap = k / Cn, co = k - tap * Cn;
+    v = w[((long)(g * Cn + co) * Cg + ci) * taps + tap];
+  }
+  TT<T>::st(out + idx, v);
+}
+
+template <typename T, bool DGRAD>
+int launch_conv(const ConvP& p, hipStream_t st) {
+  dim3 block(256);
+  if (p.Cn > 64) {
+    dim3 grid(cdiv(p.M, 128), cdiv(p.Cn, 128), p.G);
+    size_t sm = 2 * (128 + 128) * 128;
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2, DGRAD>), grid, block, sm, st, p);
+  } else if (p.Cn > 32) {
+    dim3 grid(cdiv(p.M, 128), 1, p.G);
+    size_t sm = 2 * (128 + 64) * 128;
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 4, 1, DGRAD>), grid, block, sm, st, p);
+  } else {
+    dim3 grid(cdiv(p.M, 128), 1, p.G);
+    size_t sm = 2 * (128 + 32) * 128;
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1, DGRAD>), grid, block, sm, st, p);
+  }
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_conv_stat_blocks(int B, int Ho, int Wo) { return cdiv((long)B * Ho * Wo, 128); }
+
+int y3d_conv_kpad(int dtype, int k_total) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  return cdiv(k_total, ce) * ce;
+}
+
+int y3d_pack_weight_fwd(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int Cin_g_pad, int kh, int kw, void* stream) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  Y3D_CHECK(Cin_g_pad >= Cin_g && Cin_g_pad % ce == 0, "pack_weight_fwd: Cin_g_pad=%d must be a multiple of %d", Cin_g_pad, ce);
+  int taps = kh * kw, Kpad = taps * Cin_g_pad;
+  long n = (long)Cout * Kpad;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16)
+    hipLaunchKernelGGL(pack_w_fwd_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, w_oihw, (bf16_t*)out, Cout, Cin_g, Cin_g_pad, taps, Kpad);
+  else
+    hipLaunchKernelGGL(pack_w_fwd_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, w_oihw, (float*)out, Cout, Cin_g, Cin_g_pad, taps, Kpad);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_pack_weight_dgrad(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int groups, int kh, int kw, void* stream) {
+  Y3D_CHECK(Cout % groups == 0, "pack_weight_dgrad: Cout %% groups");
+  int Cn = Cout / groups, taps = kh * kw;
+  int Kpad = y3d_conv_kpad(dtype, taps * Cn);
+  long n = (long)groups * Cin_g * Kpad;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16)
+    hipLaunchKernelGGL(pack_w_dgrad_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, w_oihw, (bf16_t*)out, groups, Cn, Cin_g, taps, Kpad);
+  else
+    hipLaunchKernelGGL(pack_w_dgrad_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, w_oihw, (float*)out, groups, Cn, Cin_g, taps, Kpad);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+static int check_align(const char* what, const void* ptr, long s0, long s1, long s2, int ce) {
+  Y3D_CHECK(((uintptr_t)ptr & 15) == 0, "%s: pointer not 16-byte aligned", what);
+  Y3D_CHECK(s0 % ce == 0 && s1 % ce == 0 && s2 % ce == 0, "%s: strides (%ld,%ld,%ld) not multiples of %d elements", what, s0, s1, s2, ce);
+  return Y3D_OK;
+}
+
+int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                   const void* w_packed, const float* bias, void* y, int64_t ysw, int Ho, int Wo, int Cout, int groups,
+                   int kh, int kw, int stride, int pad, float* stat_partials, void* stream) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "conv2d_fwd: bad dtype %d", dtype);
+  Y3D_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && groups > 0, "conv2d_fwd: empty shape");
+  Y3D_CHECK(Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd: channels not divisible by groups");
+  Y3D_CHECK((Cin / groups) % ce == 0, "conv2d_fwd: Cin/groups=%d must be a multiple of %d (pad the input)", Cin / groups, ce);
+  Y3D_CHECK(Ho == (H + 2 * pad - kh) / stride + 1 && Wo == (W + 2 * pad - kw) / stride + 1, "conv2d_fwd: output dims (%d,%d) inconsistent", Ho, Wo);
+  Y3D_CHECK(ysw >= Cout, "conv2d_fwd: ysw < Cout");
+  Y3D_CHECK(!(bias && stat_partials), "conv2d_fwd: bias and BN partials are mutually exclusive");
+  if (check_align("conv2d_fwd x", x, xsb, xsh, xsw, ce)) return Y3D_ERR_INVALID;
+  Y3D_CHECK(((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 7) == 0, "conv2d_fwd: w/y alignment");
+  Y3D_CHECK((long)B * Ho * Wo < (1L << 31), "conv2d_fwd: too many pixels");
+  ConvP p;
+  p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.part = stat_partials;
+  p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = ysw;
+  p.B = B; p.Hg = H; p.Wg = W; p.Hq = Ho; p.Wq = Wo;
+  p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+  p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
+  if (dtype == Y3D_BF16) return launch_conv<bf16_t, false>(p, (hipStream_t)stream);
+  return launch_conv<float, false>(p, (hipStream_t)stream);
+}
+
+int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
+                        const void* w_packed_dgrad, void* dx, int64_t xsw, int H, int W, int Cin, int groups, int kh, int kw,
+                        int stride, int pad, void* stream) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "conv2d_bwd_data: bad dtype %d", dtype);
+  Y3D_CHECK(Cin % groups == 0 && Cout % groups == 0, "conv2d_bwd_data: channels not divisible by groups");
+  Y3D_CHECK((Cout / groups) % ce == 0, "conv2d_bwd_data: Cout/groups=%d must be a multiple of %d", Cout / groups, ce);
+  Y3D_CHECK(xsw >= Cin, "conv2d_bwd_data: xsw < Cin");
+  if (check_align("conv2d_bwd_data dy", dy, dsb, dsh, dsw, ce)) return Y3D_ERR_INVALID;
+  ConvP p;
+  p.x = dy; p.w = w_packed_dgrad; p.bias = nullptr; p.y = dx; p.part = nullptr;
+  p.xsb = dsb; p.xsh = dsh; p.xsw = dsw; p.ysw = xsw;
+  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hq = H; p.Wq = W;
+  p.Cg = Cout / groups; p.Cn = Cin / groups; p.G = groups;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+  p.Ktot = kh * kw * p.Cg; p.Kpad = y3d_conv_kpad(dtype, p.Ktot); p.M = B * H * W;
+  if (dtype == Y3D_BF16) return launch_conv<bf16_t, true>(p, (hipStream_t)stream);
+  return launch_conv<float, true>(p, (hipStream_t)stream);
+}
+
+int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_g, int groups, int kh, int kw) {
+  int bpk = dtype == Y3D_BF16 ? 64 : 32;
+  long M = (long)B * Ho * Wo;
+  long tiles = (long)cdiv(kh * kw * Cin_g, 128) * cdiv(Cout / groups, 128) * groups;
+  long want = cdiv(1024, tiles);
+  long maxs = cdiv(M, bpk);
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return (int)want;
+}
+
+int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                          int Cin_real, const void* dy, int64_t dsw, int Ho, int Wo, int Cout, int groups, int kh, int kw,
+                          int stride, int pad, float* slab, int nsplit, float* grad_oihw, int accumulate, void* stream) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  int bpk = dtype == Y3D_BF16 ? 64 : 32;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "conv2d_bwd_weight: bad dtype %d", dtype);
+  Y3D_CHECK(Cin % groups == 0 && Cout % groups == 0, "conv2d_bwd_weight: channels not divisible by groups");
+  Y3D_CHECK((Cin / groups) % ce == 0 && (Cout / groups) % ce == 0, "conv2d_bwd_weight: per-group channels must be multiples of %d", ce);
+  Y3D_CHECK(nsplit >= 1, "conv2d_bwd_weight: nsplit");
+  Y3D_CHECK(Cin_real <= Cin && (Cin_real == Cin || groups == 1), "conv2d_bwd_weight: Cin_real");
+  if (check_align("conv2d_bwd_weight x", x, xsb, xsh, xsw, ce)) return Y3D_ERR_INVALID;
+  Y3D_CHECK(((uintptr_t)dy & 15) == 0 && dsw % ce == 0, "conv2d_bwd_weight: dy alignment");
+  WgradP p;
+  p.x = x; p.dy = dy; p.slab = slab;
+  p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.dsw = dsw;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+  p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+  p.Ktot = kh * kw * p.Cg; p.M = B * Ho * Wo; p.nsplit = nsplit;
+  p.chunk_px = cdiv(cdiv(p.M, nsplit), bpk) * bpk;
+  dim3 grid(cdiv(p.Ktot, 128), cdiv(p.Cn, 128), groups * nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  size_t sm = 4 * 16384;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), sm, st, p);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), sm, st, p);
+  Y3D_LAUNCH_CHECK();
+  long n = (long)Cout * kh * kw * p.Cg;
+  int cg_real = groups == 1 ? Cin_real : p.Cg;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, cg_real, accumulate);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

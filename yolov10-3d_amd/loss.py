@@ -1,0 +1,365 @@
+"""Losses + task-aligned assignment for the YOLOv10 (2D) and YOLOv10-3D heads — device side.
+
+Mirrors the reference interfaces (utils/loss.py: v8DetectionLoss :157, v10DetectLoss :727, DetectLoss3d :740,
+DDDetectionLoss :774; utils/tal.py: TaskAlignedAssigner :19, TaskAlignedAssigner3d :355;
+utils/keypoint_utils.py; utils/metrics.py:78 bbox_iou).  All arithmetic is fp32 (the reference runs these
+under autocast's fp32 policy), on the tensors' own device.
+
+ROUND-1 STATUS: this file expresses K13-K17 of SURVEY §2.3 with torch *device* ops (HBM-bound, <2 % of
+the step); the fused HIP assigner / loss kernels (tal.hip / loss.hip) replace these bodies behind the same
+class interface — see DESIGN.md "what is not yet hand-written".  Tie rule of the top-k is pinned to
+lowest-index-first.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .modules import make_anchors
+
+
+def ciou(b1, b2, eps=1e-7):
+    """utils/metrics.py:78-134 (xywh=False, CIoU=True) on broadcastable (...,4) boxes"""
+    x11, y11, x12, y12 = b1.unbind(-1)
+    x21, y21, x22, y22 = b2.unbind(-1)
+    w1, h1 = x12 - x11, y12 - y11 + eps
+    w2, h2 = x22 - x21, y22 - y21 + eps
+    inter = (torch.minimum(x12, x22) - torch.maximum(x11, x21)).clamp(min=0) * \
+            (torch.minimum(y12, y22) - torch.maximum(y11, y21)).clamp(min=0)
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw = torch.maximum(x12, x22) - torch.minimum(x11, x21)
+    chh = torch.maximum(y12, y22) - torch.minimum(y11, y21)
+    c2 = cw.pow(2) + chh.pow(2) + eps
+    rho2 = ((x21 + x22 - x11 - x12).pow(2) + (y21 + y22 - y11 - y12).pow(2)) / 4
+    v = (4 / math.pi ** 2) * ((w2 / h2).atan() - (w1 / h1).atan()).pow(2)
+    with torch.no_grad():
+        alpha = v / (v - iou + (1 + eps))
+    return iou - (rho2 / c2 + v * alpha)
+
+
+def keypoints_3d(center, dep, size3d, hbin, hres, calib):
+    """utils/keypoint_utils.py:11-118: 8 box corners in the camera frame, (B,N,8,3)"""
+    cu, cv, fu, fv, tx, ty = [calib[:, None, k:k + 1] for k in range(6)]
+    X = (center[..., 0:1] - cu) * dep / fu + tx
+    Y = (center[..., 1:2] - cv) * dep / fv + ty
+    loc = torch.cat((X, Y, dep), -1)
+    hl, hw, hh = size3d[..., 2:3] / 2, size3d[..., 1:2] / 2, size3d[..., 0:1] / 2
+    cx = torch.cat((hl, hl, -hl, -hl, hl, hl, -hl, -hl), -1)
+    cy = torch.cat((hw, -hw, hw, -hw, hw, -hw, hw, -hw), -1)
+    cz = torch.cat((-hh, -hh, -hh, -hh, hh, hh, hh, hh), -1)
+    corners = torch.stack((cx, cy, cz), -1)
+    bi = hbin.argmax(-1) if hbin.shape[-1] > 1 else hbin[..., 0].long()
+    res = hres.gather(-1, bi.unsqueeze(-1))[..., 0] if hres.shape[-1] > 1 else hres[..., 0]
+    ang = bi.to(res.dtype) * (2 * math.pi / 12.0) + res
+    ang = torch.where(ang > math.pi, ang - 2 * math.pi, ang)
+    ry = ang.unsqueeze(-1) + torch.arctan2(center[..., 0:1] - cu, fu)
+    ry = torch.where(ry > math.pi, ry - 2 * math.pi, ry)
+    ry = torch.where(ry < -math.pi, ry + 2 * math.pi, ry)
+    a = -ry[..., 0]
+    ca, sa = torch.cos(a), torch.sin(a)
+    one, zero = torch.ones_like(ca), torch.zeros_like(ca)
+    cxr, sxr = math.cos(math.pi / 2), math.sin(math.pi / 2)
+    Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, cxr, -sxr], [0.0, sxr, cxr]], dtype=ca.dtype, device=ca.device)
+    Ry = torch.stack((ca, zero, sa, zero, one, zero, -sa, zero, ca), -1).reshape(ca.shape + (3, 3))
+    R = torch.matmul(Rx, Ry)
+    return torch.einsum("bnji,bnkj->bnki", R, corners) + loc.unsqueeze(-2)
+
+
+def _topk_mask(metric, k, valid_gt):
+    """utils/tal.py:615-649 with lowest-index-first ties"""
+    B, n, A = metric.shape
+    order = torch.sort(metric, dim=-1, descending=True, stable=True)[1][..., :k]
+    order = torch.where(valid_gt.expand(-1, -1, k).bool(), order, torch.zeros_like(order))
+    cnt = torch.zeros(B, n, A, dtype=torch.int32, device=metric.device)
+    cnt.scatter_add_(-1, order, torch.ones_like(order, dtype=torch.int32))
+    return torch.where(cnt > 1, torch.zeros_like(cnt), cnt).to(metric.dtype)
+
+
+def _resolve(mask_pos, overlaps):
+    """utils/tal.py:728-753"""
+    n = mask_pos.shape[1]
+    fg = mask_pos.sum(-2)
+    multi = (fg.unsqueeze(1) > 1).expand(-1, n, -1)
+    onehot = torch.zeros_like(mask_pos)
+    onehot.scatter_(1, overlaps.argmax(1).unsqueeze(1), 1)
+    mask_pos = torch.where(multi, onehot, mask_pos)
+    return mask_pos.argmax(-2), mask_pos.sum(-2), mask_pos
+
+
+def _in_gts(anc, gt_bboxes, eps=1e-9):
+    lt, rb = gt_bboxes[..., None, :2], gt_bboxes[..., None, 2:]
+    return (torch.cat((anc[None, None] - lt, rb - anc[None, None]), -1).amin(-1) > eps).to(gt_bboxes.dtype)
+
+
+class TaskAlignedAssigner:
+    """utils/tal.py:19-264"""
+
+    def __init__(self, topk=13, num_classes=80, alpha=1.0, beta=6.0, eps=1e-9):
+        self.topk, self.num_classes, self.alpha, self.beta, self.eps = topk, num_classes, alpha, beta, eps
+
+    @torch.no_grad()
+    def __call__(self, pd_scores, pd_bboxes, anc, gt_labels, gt_bboxes, mask_gt):
+        B, A = pd_scores.shape[:2]
+        n, nc = gt_bboxes.shape[1], self.num_classes
+        dev = pd_scores.device
+        if n == 0:
+            return (torch.full((B, A), float(nc), device=dev), torch.zeros_like(pd_bboxes), torch.zeros_like(pd_scores),
+                    torch.zeros(B, A, dtype=torch.bool, device=dev), torch.zeros(B, A, dtype=torch.long, device=dev))
+        in_g = _in_gts(anc, gt_bboxes)
+        m = (in_g * mask_gt).bool()
+        lab = gt_labels.squeeze(-1).long()
+        sc = pd_scores.gather(2, lab.clamp(min=0)[:, None, :].expand(-1, A, -1)).permute(0, 2, 1)
+        sc = torch.where(m, sc, torch.zeros_like(sc))
+        ov = torch.where(m, ciou(gt_bboxes[:, :, None, :], pd_bboxes[:, None, :, :]).clamp(min=0), torch.zeros_like(sc))
+        align = sc.pow(self.alpha) * ov.pow(self.beta)
+        mask_pos = _topk_mask(align, self.topk, mask_gt) * in_g * mask_gt
+        gt_idx, fg, mask_pos = _resolve(mask_pos, ov)
+        flat = gt_idx + torch.arange(B, device=dev)[:, None] * n
+        t_lab = lab.flatten()[flat].clamp(min=0)
+        t_box = gt_bboxes.reshape(-1, 4)[flat]
+        t_sc = F.one_hot(t_lab, nc).to(pd_scores.dtype) * (fg > 0).unsqueeze(-1)
+        align = align * mask_pos
+        pa = align.amax(-1, keepdim=True)
+        po = (ov * mask_pos).amax(-1, keepdim=True)
+        norm = (align * po / (pa + self.eps)).amax(-2).unsqueeze(-1)
+        return t_lab, t_box, t_sc * norm, fg.bool(), gt_idx
+
+
+class TaskAlignedAssigner3d:
+    """utils/tal.py:355-753 (use_2d and use_3d, 'l1' keypoint metric, constrain_anchors: cfg/default.yaml:112-119)"""
+
+    def __init__(self, topk=8, num_classes=3, alpha=0.5, beta=3.0, gamma=3.0, eps=1e-9, use_2d=True, use_3d=True,
+                 kps_dist_metric="l1", constrain_anchors=True):
+        if not (use_2d and use_3d and kps_dist_metric == "l1" and constrain_anchors):
+            raise NotImplementedError("only the default 2D+3D / l1 / constrained assignment is built")
+        self.topk, self.num_classes, self.alpha, self.beta, self.gamma, self.eps = topk, num_classes, alpha, beta, gamma, eps
+
+    @torch.no_grad()
+    def __call__(self, pd_scores, pd_bboxes, pd_3d, anc, gts, mask_gt, stride_tensor, calibs, mean_sizes):
+        gl, gb, gc2, gs2, gc3, gs3, gd, ghb, ghr = gts
+        B, A = pd_scores.shape[:2]
+        n, nc = gb.shape[1], self.num_classes
+        dev = pd_scores.device
+        o3d, s3d, hd, dep, _ = pd_3d.split((2, 3, 24, 1, 1), -1)
+        pc3 = anc + o3d * stride_tensor
+        ps3 = mean_sizes[pd_scores.argmax(-1)] + s3d
+        lab = gl.squeeze(-1).long()
+        g_kps = keypoints_3d(gc3, gd, mean_sizes[lab.clamp(min=0)] + gs3, ghb, ghr, calibs)
+        p_kps = keypoints_3d(pc3, dep, ps3, hd[..., :12], hd[..., 12:], calibs)
+        in_g = _in_gts(anc, gb)
+        m = (in_g * mask_gt).bool()
+        sc = pd_scores.gather(2, lab.clamp(min=0)[:, None, :].expand(-1, A, -1)).permute(0, 2, 1)
+        sc = torch.where(m, sc, torch.zeros_like(sc))
+        dist = torch.zeros(B, n, A, device=dev)
+        for g in range(n):  # keeps the (B,n,A,8,3) temporary of the reference (tal.py:593-595) out of memory
+            dist[:, g] = (p_kps - g_kps[:, g:g + 1]).abs().sum((-1, -2)) / 24
+        sim = torch.where(m, 1 / torch.exp(dist), torch.zeros_like(dist))
+        ov = torch.where(m, ciou(gb[:, :, None, :], pd_bboxes[:, None, :, :]).clamp(min=0), torch.zeros_like(dist))
+        align = sc.pow(self.alpha) * ov.pow(self.beta) * sim.pow(self.gamma)
+        mask_pos = _topk_mask(align, self.topk, mask_gt) * in_g * mask_gt
+        gt_idx, fg, mask_pos = _resolve(mask_pos, sim)
+        flat = gt_idx + torch.arange(B, device=dev)[:, None] * n
+        t_lab = lab.flatten()[flat].clamp(min=0)
+
+        def take(t):
+            return t.reshape(-1, t.shape[-1])[flat]
+
+        t_sc = F.one_hot(t_lab, nc).to(pd_scores.dtype) * (fg > 0).unsqueeze(-1)
+        align = align * mask_pos
+        pa = align.amax(-1, keepdim=True)
+        po = (sim * mask_pos).amax(-1, keepdim=True)
+        norm = (align * po / (pa + self.eps)).amax(-2).unsqueeze(-1)
+        targets = [t_lab, t_sc * norm, take(gc2), take(gs2), take(gc3), take(gs3), take(gd), take(ghb), take(ghr)]
+        return targets, fg.bool(), gt_idx, p_kps, g_kps
+
+
+def _pad_targets(rows, B, width, scale):
+    """utils/loss.py:795-810"""
+    dev = rows.device
+    if rows.shape[0] == 0:
+        return torch.zeros(B, 0, width, device=dev)
+    bi = rows[:, 0].long()
+    counts = torch.bincount(bi, minlength=B)
+    nmax = int(counts.max())
+    order = torch.argsort(bi, stable=True)
+    start = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(rows.shape[0], device=dev) - start[bi[order]]
+    out = torch.zeros(B, nmax, width, device=dev)
+    out[bi[order], pos] = rows[order, 1:]
+    xywh = out[..., 1:5] * scale
+    xy, wh = xywh[..., :2], xywh[..., 2:]
+    out[..., 1:5] = torch.cat((xy - wh / 2, xy + wh / 2), -1)
+    return out
+
+
+def _flatten_maps(feats):
+    """list of (B, no, H, W) NHWC maps -> (B, A, no) fp32 (a free view per level + one cat)"""
+    B, no = feats[0].shape[:2]
+    return torch.cat([f.permute(0, 2, 3, 1).reshape(B, -1, no) for f in feats], 1).float()
+
+
+class DDDetectionLoss:
+    """utils/loss.py:774-963"""
+
+    def __init__(self, model, tal_topk=10):
+        h = model.args
+        m = model.model[-1]
+        self.hyp = h
+        self.stride = [float(s) for s in m.stride]
+        self.nc, self.no = m.nc, m.no
+        self.assigner = TaskAlignedAssigner3d(topk=tal_topk, num_classes=self.nc, alpha=h.tal_alpha, beta=h.tal_beta, gamma=h.tal_gamma,
+                                              use_2d=h.tal_2d, use_3d=h.tal_3d, kps_dist_metric=h.kps_dist_metric,
+                                              constrain_anchors=h.constrain_anchors)
+        if getattr(h, "distillation", False):
+            raise NotImplementedError("distillation needs the DINOv2 teacher (network); pinned off (SURVEY §0.5)")
+
+    def __call__(self, preds, batch, embeddings=None):
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        dev = feats[0].device
+        B = feats[0].shape[0]
+        cat = _flatten_maps(feats)
+        sc, o2d, s2d, o3d, s3d, hd, dep, dun = cat.split((self.nc, 2, 2, 2, 3, 24, 1, 1), -1)
+        pred_2d = torch.cat((o2d, s2d), -1)
+        pred_3d = torch.cat((o3d, s3d, hd, dep, dun), -1)
+        H, W = feats[0].shape[2:]
+        imgsz = torch.tensor([H, W], dtype=torch.float32, device=dev) * self.stride[0]
+        anc, st = make_anchors([f.shape[2:] for f in feats], self.stride, dev)
+        rows = torch.cat([batch[k].to(dev).float().view(batch[k].shape[0], -1) for k in
+                          ("batch_idx", "cls", "bboxes", "center_2d", "size_2d", "center_3d", "size_3d", "depth", "heading_bin", "heading_res")], 1)
+        g = _pad_targets(rows, B, 17, imgsz[[1, 0, 1, 0]])
+        loss = torch.zeros(6, device=dev)
+        if g.shape[1] == 0:
+            return loss.sum() * B, loss  # reference: graph-less zeros (loss.py:873-877); callers skip the step
+        gts = g.split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)
+        mask_gt = (gts[1].sum(2, keepdim=True) > 0).float()
+        centers = anc + pred_2d[..., :2]
+        pb = torch.cat((centers - pred_2d[..., 2:] / 2, centers + pred_2d[..., 2:] / 2), -1) * st
+        targets, fg, gt_idx, _, _ = self.assigner(sc.detach().sigmoid(), pb.detach(), pred_3d.detach(), anc * st, gts, mask_gt, st,
+                                                  batch["calib"].to(dev).float(), batch["mean_sizes"].to(dev).float())
+        _, t_sc, t_c2, t_s2, t_c3, t_s3, t_d, t_hb, t_hr = targets
+        tss = t_sc.sum().clamp(min=1)
+        anc_px = anc * st
+        h = self.hyp
+        p2 = (pred_2d * st)[fg]
+        off_l = F.l1_loss(p2[..., :2], (t_c2 - anc_px)[fg], reduction="mean")
+        siz_l = F.l1_loss(p2[..., 2:], t_s2[fg], reduction="mean")
+        l0 = (siz_l + off_l) / tss * h.loss2d
+        l1 = F.binary_cross_entropy_with_logits(sc, t_sc, reduction="none").sum() / tss * h.cls
+        p3 = pred_3d[fg]
+        pd, pu = p3[..., -2], p3[..., -1]
+        td = t_d[fg].squeeze(-1)
+        l2 = (1.4142 * torch.exp(-0.5 * pu) * (pd - td).abs() + 0.5 * pu).sum() / tss * h.depth
+        l3 = F.l1_loss((pred_3d[..., :2] * st)[fg], (t_c3 - anc_px)[fg], reduction="mean") / tss * h.offset3d
+        l4 = F.l1_loss(p3[..., 2:5], t_s3[fg], reduction="sum") / tss * h.size3d
+        ph = p3[..., 5:29]
+        tb = t_hb[fg].view(-1).long()
+        ce = F.cross_entropy(ph[..., :12], tb, reduction="sum")
+        reg = F.l1_loss(ph[..., 12:].gather(1, tb.view(-1, 1)).squeeze(1), t_hr[fg].view(-1), reduction="sum")
+        l5 = (ce + reg) / tss * h.heading
+        loss = torch.stack((l0, l1, l2, l3, l4, l5))
+        self.last_assignment = (fg, gt_idx)
+        return loss.sum() * B, loss
+
+
+class DetectLoss3d:
+    """utils/loss.py:740-771"""
+
+    def __init__(self, model):
+        self.one2many = DDDetectionLoss(model, tal_topk=model.args.tal_topk)
+        self.one2one = DDDetectionLoss(model, tal_topk=1)
+
+    def __call__(self, preds, batch):
+        l1, i1 = self.one2one(preds["one2one"], batch, embeddings=preds.get("o2o_embs"))
+        if preds.get("one2many", None):
+            lm, im = self.one2many(preds["one2many"], batch, embeddings=preds.get("o2m_embs"))
+            return lm + l1, torch.cat((im, i1))
+        return torch.zeros(1), i1
+
+
+class v8DetectionLoss:
+    """utils/loss.py:157-257 (+BboxLoss :73-113)"""
+
+    def __init__(self, model, tal_topk=10):
+        m = model.model[-1]
+        self.hyp = model.args
+        self.stride = [float(s) for s in m.stride]
+        self.nc, self.no, self.reg_max = m.nc, m.no, m.reg_max
+        self.assigner = TaskAlignedAssigner(topk=tal_topk, num_classes=self.nc, alpha=0.5, beta=6.0)
+
+    def __call__(self, preds, batch):
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        dev = feats[0].device
+        B = feats[0].shape[0]
+        cat = _flatten_maps(feats)
+        dist, sc = cat.split((self.reg_max * 4, self.nc), -1)
+        H, W = feats[0].shape[2:]
+        imgsz = torch.tensor([H, W], dtype=torch.float32, device=dev) * self.stride[0]
+        anc, st = make_anchors([f.shape[2:] for f in feats], self.stride, dev)
+        rows = torch.cat((batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"]), 1).to(dev).float()
+        g = _pad_targets(rows, B, 5, imgsz[[1, 0, 1, 0]])
+        gl, gb = g.split((1, 4), 2)
+        mask_gt = (gb.sum(2, keepdim=True) > 0).float()
+        A = dist.shape[1]
+        proj = torch.arange(self.reg_max, dtype=torch.float32, device=dev)
+        d = dist.view(B, A, 4, self.reg_max).softmax(3).matmul(proj)
+        pb = torch.cat((anc - d[..., :2], anc + d[..., 2:]), -1)
+        _, t_box, t_sc, fg, gt_idx = self.assigner(sc.detach().sigmoid(), pb.detach() * st, anc * st, gl, gb, mask_gt)
+        tss = t_sc.sum().clamp(min=1)
+        l_cls = F.binary_cross_entropy_with_logits(sc, t_sc, reduction="none").sum() / tss
+        l_box = torch.zeros((), device=dev)
+        l_dfl = torch.zeros((), device=dev)
+        if fg.sum():
+            t_box = t_box / st
+            w = t_sc.sum(-1)[fg].unsqueeze(-1)
+            iou = ciou(pb[fg], t_box[fg]).unsqueeze(-1)
+            l_box = ((1.0 - iou) * w).sum() / tss
+            ltrb = torch.cat((anc - t_box[..., :2], t_box[..., 2:] - anc), -1).clamp(0, self.reg_max - 1 - 0.01)[fg]
+            pdist = dist[fg].view(-1, self.reg_max)
+            tl = ltrb.long()
+            tr = tl + 1
+            wl = tr - ltrb
+            wr = 1 - wl
+            dfl = (F.cross_entropy(pdist, tl.view(-1), reduction="none").view(tl.shape) * wl +
+                   F.cross_entropy(pdist, tr.view(-1), reduction="none").view(tl.shape) * wr).mean(-1, keepdim=True)
+            l_dfl = (dfl * w).sum() / tss
+        loss = torch.stack((l_box * self.hyp.box, l_cls * self.hyp.cls, l_dfl * self.hyp.dfl))
+        self.last_assignment = (fg, gt_idx)
+        return loss.sum() * B, loss.detach()
+
+
+class v10DetectLoss:
+    """utils/loss.py:727-737"""
+
+    def __init__(self, model):
+        self.one2many = v8DetectionLoss(model, tal_topk=10)
+        self.one2one = v8DetectionLoss(model, tal_topk=1)
+
+    def __call__(self, preds, batch):
+        lm, im = self.one2many(preds["one2many"], batch)
+        l1, i1 = self.one2one(preds["one2one"], batch)
+        return lm + l1, torch.cat((im, i1))
+
+
+def v10_3Dpostprocess(preds, max_det, nc=3):
+    """utils/ops.py:867-880"""
+    assert preds.shape[-1] == nc + 35
+    scores, reg = preds.split([nc, preds.shape[-1] - nc], -1)
+    _, idx = torch.topk(scores.amax(-1), max_det, dim=-1)
+    reg = reg.gather(1, idx.unsqueeze(-1).expand(-1, -1, reg.shape[-1]))
+    scores = scores.gather(1, idx.unsqueeze(-1).expand(-1, -1, nc))
+    s2, idx2 = torch.topk(scores.flatten(1), max_det, dim=-1)
+    return reg.gather(1, (idx2 // nc).unsqueeze(-1).expand(-1, -1, reg.shape[-1])), s2, idx2 % nc
+
+
+def v10postprocess(preds, max_det, nc=80):
+    """utils/ops.py:852-865"""
+    assert 4 + nc == preds.shape[-1]
+    boxes, scores = preds.split([4, nc], -1)
+    _, idx = torch.topk(scores.amax(-1), max_det, dim=-1)
+    boxes = boxes.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4))
+    scores = scores.gather(1, idx.unsqueeze(-1).expand(-1, -1, nc))
+    s2, idx2 = torch.topk(scores.flatten(1), max_det, dim=-1)
+    return boxes.gather(1, (idx2 // nc).unsqueeze(-1).expand(-1, -1, 4)), s2, idx2 % nc

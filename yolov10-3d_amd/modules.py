@@ -1,0 +1,529 @@
+"""Host-side mirror of the reference's nn.Modules for the YOLOv10 / YOLOv10-3D path.
+
+Same class names, constructor signatures, attribute names and state_dict key layout as
+ultralytics/nn/modules/{conv,block,head}.py — so the yaml tables and reference
+checkpoints apply unchanged — but every forward/backward body runs on liby3d_hip.so
+(see ops.py).  nn.Conv2d / nn.BatchNorm2d objects are kept as *parameter containers* only
+(their own forward is never called).
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import Y3DError
+
+
+def autopad(k, p=None, d=1):
+    """reference conv.py:28-34"""
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def _flush_nbt(module, prefix, keep_vars):
+    if module._nbt_pending:
+        module.bn.num_batches_tracked += module._nbt_pending
+        module._nbt_pending = 0
+
+
+class Conv(nn.Module):
+    """reference conv.py:103-126: act(bn(conv(x))); one fused HIP sequence (conv -> BN stats -> BN+SiLU[+res])."""
+
+    default_act = nn.SiLU()
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True, deform=False):
+        super().__init__()
+        if deform:
+            raise NotImplementedError("deform=True is not used by any v10 / v10-3D yaml (SURVEY §8c)")
+        if isinstance(k, (tuple, list)):
+            assert k[0] == k[1], "square kernels only"
+            k = k[0]
+        if d != 1:
+            raise NotImplementedError("dilation != 1 is not on the YOLOv10 path")
+        self.deform = False
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(_flush_nbt)
+
+    # kernel-facing views of the configuration
+    @property
+    def k(self):
+        return self.conv.kernel_size[0]
+
+    @property
+    def s(self):
+        return self.conv.stride[0]
+
+    @property
+    def p(self):
+        return self.conv.padding[0]
+
+    @property
+    def g(self):
+        return self.conv.groups
+
+    @property
+    def eps(self):
+        return float(self.bn.eps)
+
+    @property
+    def momentum(self):
+        return float(self.bn.momentum)
+
+    @property
+    def has_act(self):
+        if isinstance(self.act, nn.SiLU):
+            return True
+        if isinstance(self.act, nn.Identity):
+            return False
+        raise Y3DError(f"activation {type(self.act).__name__} has no HIP kernel (SiLU / Identity only)")
+
+    def forward(self, x, res=None, res_mode=0):
+        """res_mode 1: act(bn(conv(x))) + res   (Bottleneck / CIB / PSA shortcuts)
+           res_mode 2: act(bn(conv(x)) + res)   (RepVGGDW)"""
+        return ops.ConvBNActFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias, res, res_mode if res is not None else 0, self)
+
+    forward_fuse = None  # BN folding is done by fuse.py on the packed weights, not by swapping forwards
+
+
+class DWConv(Conv):
+    """reference conv.py:172-177"""
+
+    def __init__(self, c1, c2, k=1, s=1, d=1, act=True):
+        super().__init__(c1, c2, k, s, g=math.gcd(c1, c2), d=d, act=act)
+
+
+class Concat(nn.Module):
+    """reference conv.py:394-404"""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        assert self.d == 1
+        return cat(x)
+
+
+def cat(xs):
+    c = ops.ce(ops.compute_dtype())
+    if all(t.shape[1] % c == 0 for t in xs):
+        return ops.ConcatFn.apply(*xs)
+    return torch.cat([t.to(ops.compute_dtype()) for t in xs], 1)  # channel counts that are not 16-byte chunks (plumbing)
+
+
+class Upsample(nn.Module):
+    """nn.Upsample(None, 2, 'nearest') rows of the yaml tables"""
+
+    def __init__(self, size=None, scale_factor=None, mode="nearest"):
+        super().__init__()
+        if size is not None or int(scale_factor) != 2 or mode != "nearest":
+            raise NotImplementedError("only nearest 2x upsampling is on the YOLOv10 path")
+        self.scale_factor, self.mode = scale_factor, mode
+
+    def forward(self, x):
+        return ops.Upsample2xFn.apply(x)
+
+
+class Bottleneck(nn.Module):
+    """reference block.py:327-342"""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        return self.cv2(self.cv1(x), x, 1) if self.add else self.cv2(self.cv1(x))
+
+
+class C2f(nn.Module):
+    """reference block.py:216-239"""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def forward(self, x):
+        y = list(self.cv1(x).chunk(2, 1))
+        y.extend(m(y[-1]) for m in self.m)
+        return self.cv2(cat(y))
+
+
+class SPPF(nn.Module):
+    """reference block.py:158-178"""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.k = k
+
+    def forward(self, x):
+        x = self.cv1(x)
+        y1 = ops.MaxPoolFn.apply(x, self.k)
+        y2 = ops.MaxPoolFn.apply(y1, self.k)
+        y3 = ops.MaxPoolFn.apply(y2, self.k)
+        return self.cv2(cat((x, y1, y2, y3)))
+
+
+class RepVGGDW(nn.Module):
+    """reference block.py:702-735: SiLU(dw7x7+BN + dw3x3+BN)"""
+
+    def __init__(self, ed):
+        super().__init__()
+        self.conv = Conv(ed, ed, 7, 1, 3, g=ed, act=False)
+        self.conv1 = Conv(ed, ed, 3, 1, 1, g=ed, act=False)
+        self.dim = ed
+        self.act = nn.SiLU()
+        self.conv.act = nn.SiLU()  # the 7x7 branch applies the SiLU after adding the 3x3 branch (res_mode 2)
+
+    def forward(self, x):
+        return self.conv(x, self.conv1(x), 2)
+
+
+class CIB(nn.Module):
+    """reference block.py:737-758"""
+
+    def __init__(self, c1, c2, shortcut=True, e=0.5, lk=False):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = nn.Sequential(
+            Conv(c1, c1, 3, g=c1),
+            Conv(c1, 2 * c_, 1),
+            Conv(2 * c_, 2 * c_, 3, g=2 * c_) if not lk else RepVGGDW(2 * c_),
+            Conv(2 * c_, c2, 1),
+            Conv(c2, c2, 3, g=c2),
+        )
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        y = x
+        for i in range(4):
+            y = self.cv1[i](y)
+        return self.cv1[4](y, x, 1) if self.add else self.cv1[4](y)
+
+
+class C2fCIB(C2f):
+    """reference block.py:760-768"""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, lk=False, g=1, e=0.5):
+        super().__init__(c1, c2, n, shortcut, g, e)
+        self.m = nn.ModuleList(CIB(self.c, self.c, shortcut, e=1.0, lk=lk) for _ in range(n))
+
+
+class Attention(nn.Module):
+    """reference block.py:771-797"""
+
+    def __init__(self, dim, num_heads=8, attn_ratio=0.5):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.key_dim = int(self.head_dim * attn_ratio)
+        self.scale = self.key_dim ** -0.5
+        nh_kd = self.key_dim * num_heads
+        h = dim + nh_kd * 2
+        self.qkv = Conv(dim, h, 1, act=False)
+        self.proj = Conv(dim, dim, 1, act=False)
+        self.pe = Conv(dim, dim, 3, 1, g=dim, act=False)
+
+    def forward(self, x, res=None):
+        """returns proj(attn(x) + pe(v)) (+ res when given: the `b + attn(b)` of PSA.forward)"""
+        qkv = self.qkv(x)
+        o, v = ops.AttentionFn.apply(qkv, self.num_heads, self.key_dim, self.head_dim, self.scale)
+        y = self.pe(v, o, 1)  # bn(dw3x3(v)) + o
+        return self.proj(y, res, 1) if res is not None else self.proj(y)
+
+
+class PSA(nn.Module):
+    """reference block.py:799-818"""
+
+    def __init__(self, c1, c2, e=0.5):
+        super().__init__()
+        assert c1 == c2
+        self.c = int(c1 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv(2 * self.c, c1, 1)
+        self.attn = Attention(self.c, attn_ratio=0.5, num_heads=self.c // 64)
+        self.ffn = nn.Sequential(Conv(self.c, self.c * 2, 1), Conv(self.c * 2, self.c, 1, act=False))
+
+    def forward(self, x):
+        a, b = self.cv1(x).split((self.c, self.c), dim=1)
+        b = self.attn(b, res=b)
+        b = self.ffn[1](self.ffn[0](b), b, 1)
+        return self.cv2(cat((a, b)))
+
+
+class SCDown(nn.Module):
+    """reference block.py:820-827"""
+
+    def __init__(self, c1, c2, k, s):
+        super().__init__()
+        self.cv1 = Conv(c1, c2, 1, 1)
+        self.cv2 = Conv(c2, c2, k=k, s=s, g=c2, act=False)
+
+    def forward(self, x):
+        return self.cv2(self.cv1(x))
+
+
+class DFL(nn.Module):
+    """reference block.py:44-62 (parameter container; the expectation is computed in head/loss code)"""
+
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+    def forward(self, x):
+        b, _, a = x.shape
+        return (x.view(b, 4, self.c1, a).softmax(2) * self.conv.weight.view(1, 1, self.c1, 1).to(x.dtype)).sum(2)
+
+
+def make_anchors(shapes, strides, device, grid_cell_offset=0.5):
+    """reference utils/tal.py:300-312 from (h, w) shapes"""
+    pts, st = [], []
+    for (h, w), s in zip(shapes, strides):
+        sx = torch.arange(w, device=device, dtype=torch.float32) + grid_cell_offset
+        sy = torch.arange(h, device=device, dtype=torch.float32) + grid_cell_offset
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        pts.append(torch.stack((xx, yy), -1).view(-1, 2))
+        st.append(torch.full((h * w, 1), float(s), dtype=torch.float32, device=device))
+    return torch.cat(pts), torch.cat(st)
+
+
+def _proj(branches, feats):
+    """final 1x1+bias convs of several branches -> one NHWC map (their torch.cat)"""
+    n = len(branches)
+    return ops.HeadProjFn.apply(n, *feats, *[b.weight for b in branches], *[b.bias for b in branches])
+
+
+class v10Detect3d(nn.Module):
+    """reference head.py:545-975 (dsconv / predecessors / common_head / half_channels / fgdm off, as in every shipped yaml)."""
+
+    max_det = 50
+    dynamic = False
+    export = False
+    shape = None
+
+    def __init__(self, nc=80, ch=(), dsconv=False, channels=None, use_predecessors=False, detach_predecessors=True,
+                 deform=False, common_head=False, num_scales=3, half_channels=False, fgdm_predictor=False,
+                 kernel_size_1=3, kernel_size_2=3):
+        super().__init__()
+        assert channels is not None
+        for name, flag in (("dsconv", dsconv), ("use_predecessors", use_predecessors), ("deform", deform),
+                           ("common_head", common_head), ("half_channels", half_channels), ("fgdm_predictor", fgdm_predictor)):
+            if flag:
+                raise NotImplementedError(f"{name}=True is not used by any shipped v10-3D yaml")
+        kernel_size_1 = 3 if kernel_size_1 is None else kernel_size_1  # reference bug: tasks.py:940 passes None
+        kernel_size_2 = 3 if kernel_size_2 is None else kernel_size_2
+        self.nc = nc
+        self.nl = num_scales
+        self.output_channels = {"cls": nc, "o2d": 2, "s2d": 2, "o3d": 2, "s3d": 3, "hd": 24, "dep": 1, "dep_un": 1}
+        self.no = sum(self.output_channels.values())
+        self.stride = torch.zeros(self.nl)
+        self.kernel_size_1, self.kernel_size_2 = kernel_size_1, kernel_size_2
+        self.patch_size = (kernel_size_1 - 1) + (kernel_size_2 - 1) + 1
+        self.dep_norm = 65.0
+        ch = [ch[i] for i in range(self.nl)]
+        for name, out in self.output_channels.items():
+            setattr(self, name, self.build_head(ch, channels[name + "_c"], out))
+        self.o2o_heads = nn.ModuleList([self.cls, self.o2d, self.s2d, self.o3d, self.s3d, self.hd, self.dep, self.dep_un])
+        self.o2m_heads = copy.deepcopy(self.o2o_heads)
+
+    def build_head(self, in_channels, mid, out):
+        return nn.ModuleList(nn.Sequential(Conv(x, mid, self.kernel_size_1), Conv(mid, mid, self.kernel_size_2), nn.Conv2d(mid, out, 1))
+                             for x in in_channels)
+
+    # ---- dense (training) path: head.py:718-753 -------------------------------------------------------------
+    def forward_feat(self, x, heads):
+        ys, embs = [], []
+        for i in range(self.nl):
+            feats, emb = [], None
+            for j, module in enumerate(heads):
+                e = module[i][0](x[i])
+                if j == 6:
+                    emb = e
+                feats.append(module[i][1](e))
+            ys.append(_proj([module[i][2] for module in heads], feats))
+            embs.append(emb)
+        return ys, embs
+
+    # ---- sparse (eval) path: head.py:656-716 -----------------------------------------------------------------
+    def select_candidates(self, scores):
+        B, _, H, W = scores.shape
+        m = scores.float().amax(1).reshape(B, -1)
+        idx = torch.topk(m, self.max_det, dim=1, largest=True)[1]
+        return idx // W, idx % W
+
+    def inference_forward_feat(self, x, heads):
+        ps, pad = self.patch_size, self.patch_size // 2
+        outs_ch = list(self.output_channels.values())
+        ys = []
+        for i in range(self.nl):
+            xi = x[i]
+            B, C, H, W = xi.shape
+            cls = _proj([heads[0][i][2]], [heads[0][i][1](heads[0][i][0](xi))])
+            rows, cols = self.select_candidates(cls)  # (B, K)
+            K = rows.shape[1]
+            bidx = torch.arange(B, device=xi.device).repeat_interleave(K)
+            rows, cols = rows.reshape(-1), cols.reshape(-1)
+            xp = torch.nn.functional.pad(xi, (pad, pad, pad, pad))
+            dr = torch.arange(ps, device=xi.device)
+            patches = xp[bidx[:, None, None], :, (rows[:, None] + dr)[:, :, None], (cols[:, None] + dr)[:, None, :]]  # (BK, ps, ps, C)
+            patches = patches.permute(0, 3, 1, 2)  # logical NCHW over NHWC memory
+            feats = []
+            for j in range(1, 8):
+                br = heads[j][i]
+                p0, p1 = br[0].conv.padding, br[1].conv.padding
+                br[0].conv.padding, br[1].conv.padding = (0, 0), (0, 0)  # patch semantics: both convs unpadded (head.py:706-708)
+                try:
+                    feats.append(br[1](br[0](patches)))
+                finally:
+                    br[0].conv.padding, br[1].conv.padding = p0, p1  # unlike the reference we do not leave the module mutated
+            reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
+            full = torch.zeros(B, H, W, self.no, dtype=cls.dtype, device=xi.device)
+            full[..., : self.nc] = cls.permute(0, 2, 3, 1)
+            full[bidx, rows, cols, self.nc:] = reg
+            ys.append(full.permute(0, 3, 1, 2))
+        return ys
+
+    def decode(self, ys):
+        """head.py:755-797: (B, no, A) fp32 with xyxy px boxes and centre-3d px."""
+        B = ys[0].shape[0]
+        cat_ = torch.cat([y.permute(0, 2, 3, 1).reshape(B, -1, self.no) for y in ys], 1).float().permute(0, 2, 1)
+        anc, st = make_anchors([y.shape[2:] for y in ys], self.stride.tolist(), ys[0].device)
+        anc, st = anc.t(), st.t()
+        cls, o2d, s2d, o3d, s3d, hd, dep, dep_un = cat_.split((self.nc, 2, 2, 2, 3, 24, 1, 1), 1)
+        s2 = s2d * st
+        c2 = (o2d + anc) * st
+        bbox = torch.cat((c2 - s2 / 2, c2 + s2 / 2), 1)
+        c3 = (o3d + anc) * st
+        return torch.cat((cls, bbox, c3, s3d, hd, dep, dep_un), 1)
+
+    def forward(self, x):
+        x = list(x[: self.nl])
+        if not self.training:
+            maps = self.inference_forward_feat([xi.detach() for xi in x], self.o2o_heads)
+            return {"one2one": (self.decode(maps), maps), "o2o_embs": None}
+        one2one, o2o_embs = self.forward_feat([xi.detach() for xi in x], self.o2o_heads)
+        one2many, o2m_embs = self.forward_feat(x, self.o2m_heads)
+        return {"one2many": one2many, "one2one": one2one, "o2m_embs": o2m_embs, "o2o_embs": o2o_embs, "depth_maps": torch.empty(1)}
+
+    def bias_init(self):
+        """reference head.py:847-871 (KITTI 1280x384 prior hard-coded there)"""
+        if self.nl == 1:
+            deps, ranges = [40], [[-3.5, 3.5]]
+        elif self.nl == 2:
+            deps, ranges = [45, 20], [[-2, 2], [-2, 2]]
+        elif self.nl == 3:
+            deps, ranges = [45, 25, 10], [[-2, 2], [-1.5, 1.5], [-1, 1]]
+        else:
+            raise RuntimeError("Initialization only set for 1 and 3 scales")
+        for i in range(self.nl):
+            s = float(self.stride[i])
+            self.cls[i][-1].bias.data[: self.nc] = math.log(5 / self.nc / ((1280 / s) * (384 / s)))
+            self.s2d[i][-1].bias.data.fill_(6)
+            self.o2d[i][-1].bias.data.fill_(0)
+            self.o3d[i][-1].bias.data.fill_(0)
+            self.s3d[i][-1].bias.data.fill_(0.0)
+            nn.init.normal_(self.s3d[i][-1].weight, std=0.05)
+            self.dep[i][-1].bias.data.fill_(deps[i])
+            nn.init.uniform_(self.dep[i][-1].weight, a=ranges[i][0], b=ranges[i][1])
+        self.o2o_heads = nn.ModuleList([self.cls, self.o2d, self.s2d, self.o3d, self.s3d, self.hd, self.dep, self.dep_un])
+        self.o2m_heads = copy.deepcopy(self.o2o_heads)
+
+
+class Detect(nn.Module):
+    """reference head.py:22-109 (YOLOv8 detect head; base of v10Detect)"""
+
+    dynamic = False
+    export = False
+    shape = None
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], min(self.nc, 100))
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
+        self.dfl = DFL(self.reg_max)
+
+    def forward_feat(self, x, cv2, cv3):
+        ys = []
+        for i in range(self.nl):
+            f2 = cv2[i][1](cv2[i][0](x[i]))
+            f3 = x[i]
+            for sub in list(cv3[i])[:-1]:
+                f3 = sub(f3)
+            ys.append(_proj([cv2[i][2], cv3[i][2]], [f2, f3]))
+        return ys
+
+    def inference(self, ys):
+        """head.py:53-79: (B, 4+nc, A): xywh px boxes + sigmoid scores"""
+        B = ys[0].shape[0]
+        cat_ = torch.cat([y.permute(0, 2, 3, 1).reshape(B, -1, self.no) for y in ys], 1).float().permute(0, 2, 1)
+        anc, st = make_anchors([y.shape[2:] for y in ys], self.stride.tolist(), ys[0].device)
+        anc, st = anc.t(), st.t()
+        box, cls = cat_.split((self.reg_max * 4, self.nc), 1)
+        d = self.dfl(box)
+        lt, rb = d.split([2, 2], 1)
+        x1y1, x2y2 = anc.unsqueeze(0) - lt, anc.unsqueeze(0) + rb
+        dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st
+        return torch.cat((dbox, cls.sigmoid()), 1), ys
+
+    def forward(self, x):
+        y = self.forward_feat(x, self.cv2, self.cv3)
+        return y if self.training else self.inference(y)
+
+    def bias_init(self):
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
+
+
+class v10Detect(Detect):
+    """reference head.py:505-543"""
+
+    max_det = 300
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__(nc, ch)
+        c3 = max(ch[0], min(self.nc, 100))
+        self.cv3 = nn.ModuleList(nn.Sequential(nn.Sequential(Conv(x, x, 3, g=x), Conv(x, c3, 1)),
+                                               nn.Sequential(Conv(c3, c3, 3, g=c3), Conv(c3, c3, 1)),
+                                               nn.Conv2d(c3, self.nc, 1)) for x in ch)
+        self.one2one_cv2 = copy.deepcopy(self.cv2)
+        self.one2one_cv3 = copy.deepcopy(self.cv3)
+
+    def forward(self, x):
+        one2one = self.forward_feat([xi.detach() for xi in x], self.one2one_cv2, self.one2one_cv3)
+        one2many = self.forward_feat(x, self.cv2, self.cv3)
+        if self.training:
+            return {"one2many": one2many, "one2one": one2one}
+        return {"one2many": self.inference(one2many), "one2one": self.inference(one2one)}
+
+    def bias_init(self):
+        super().bias_init()
+        for a, b, s in zip(self.one2one_cv2, self.one2one_cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)

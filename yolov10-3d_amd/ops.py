@@ -1,0 +1,459 @@
+"""Autograd glue between torch tensors and the y3d C ABI (include/y3d.h).
+
+PyTorch is plumbing here (device memory, streams, the autograd tape); every forward/backward body
+below is a sequence of liby3d_hip.so launches on the current HIP stream.  Tensors keep the logical
+NCHW shape of the reference's modules but live in NHWC ("channels last") memory in the compute
+dtype (bf16 by default, fp32 for the parity mode).
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import BF16, F32, Y3DError, lib
+
+_COMPUTE_DTYPE = torch.bfloat16
+
+
+def set_compute_dtype(dt: torch.dtype):
+    """torch.bfloat16 (performance mode) or torch.float32 (parity mode, exact-f32 MFMA)."""
+    global _COMPUTE_DTYPE
+    if dt not in (torch.bfloat16, torch.float32):
+        raise ValueError("compute dtype must be torch.bfloat16 or torch.float32")
+    _COMPUTE_DTYPE = dt
+
+
+def compute_dtype() -> torch.dtype:
+    return _COMPUTE_DTYPE
+
+
+def code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise Y3DError(f"unsupported tensor dtype {dt}")
+
+
+def ce(dt: torch.dtype) -> int:
+    return 8 if dt == torch.bfloat16 else 4
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(x: torch.Tensor):
+    if not x.is_cuda:
+        raise Y3DError("the y3d HIP path needs tensors on a HIP device (there is no CPU fallback)")
+
+
+def nhwc_empty(B, C, H, W, dtype, device):
+    """logical (B,C,H,W), memory (B,H,W,C)"""
+    return torch.empty((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def is_nhwc(x: torch.Tensor) -> bool:
+    return x.dim() == 4 and (x.stride(1) == 1 or x.shape[1] == 1)
+
+
+def px_dense(x: torch.Tensor) -> bool:
+    """element (b,h,w,c) at ((b*H + h)*W + w) * stride(3) + c  (size-1 dims may carry arbitrary strides)"""
+    B, C, H, W = x.shape
+    sw = x.stride(3)
+    return is_nhwc(x) and sw >= C and (H == 1 or x.stride(2) == W * sw) and (B == 1 or x.stride(0) == H * W * sw)
+
+
+def to_nhwc(x: torch.Tensor, dtype=None, dense=False) -> torch.Tensor:
+    """Return x as an NHWC tensor of the compute dtype, 16-byte aligned; copies only when needed."""
+    dtype = dtype or _COMPUTE_DTYPE
+    c = ce(dtype)
+    ok = (x.dtype == dtype and is_nhwc(x) and x.data_ptr() % 16 == 0 and x.stride(0) % c == 0 and x.stride(2) % c == 0
+          and x.stride(3) % c == 0 and (not dense or px_dense(x)))
+    if ok:
+        return x
+    B, C, H, W = x.shape
+    out = nhwc_empty(B, C, H, W, dtype, x.device)
+    out.copy_(x)
+    return out
+
+
+def s3(x):
+    return x.stride(0), x.stride(2), x.stride(3)
+
+
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
+# ------------------------------------------------------------------------------------------------------
+class ConvBNActFn(torch.autograd.Function):
+    """act(bn(conv(x))) (+res)   — reference nn/modules/conv.py:120-122 plus the residual adds of
+    block.py:342,711,758,816-817 fused into the BN-apply kernel.
+
+    `m` is the owning Conv module (non-tensor): k, s, p, g, act, BN buffers/eps/momentum, training flag."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, res, res_mode, m):
+        L = lib()
+        _require_gpu(x)
+        dtype = _COMPUTE_DTYPE
+        dt, c = code(dtype), ce(dtype)
+        st = stream()
+        dev = x.device
+        B, Cin, H, W = x.shape
+        Cout, Cg_w, kh, kw = weight.shape
+        k, s, p, g = m.k, m.s, m.p, m.g
+        assert kh == k and kw == k and Cin // g == Cg_w, "Conv: weight shape does not match input"
+        Ho = (H + 2 * p - k) // s + 1
+        Wo = (W + 2 * p - k) // s + 1
+        M = B * Ho * Wo
+        dw = g > 1 and g == Cin and g == Cout
+        training = m.training
+        # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
+        Cin_k = Cin
+        if Cin % c != 0:
+            if g != 1:
+                raise Y3DError(f"grouped conv with {Cin} channels is not 16-byte chunkable")
+            Cin_k = (Cin + c - 1) // c * c
+            xin = nhwc_empty(B, Cin_k, H, W, dtype, dev)
+            L.nchw_to_nhwc(dt, x.float().contiguous().data_ptr(), xin.data_ptr(), B, Cin, H, W, Cin_k, st)
+        else:
+            xin = to_nhwc(x, dtype)
+        sb, sh, sw = s3(xin)
+        y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        w32 = weight.detach()
+        if w32.dtype != torch.float32 or not w32.is_contiguous():
+            w32 = w32.float().contiguous()
+        part = None
+        if dw:
+            if Cout % c != 0:
+                raise Y3DError(f"depth-wise conv with {Cout} channels is not 16-byte chunkable")
+            nblk = L.dw_blocks(M)
+            if training:
+                part = _f32(nblk * Cout * 2, dev)
+            wp = _f32(k * k * Cout, dev)
+            L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+            L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
+                           part.data_ptr() if training else None, st)
+        else:
+            nblk = L.conv_stat_blocks(B, Ho, Wo)
+            if training:
+                part = _f32(nblk * Cout * 2, dev)
+            Cg_pad = Cin_k // g
+            wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
+            L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
+            L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
+                         k, k, s, p, part.data_ptr() if training else None, st)
+        stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
+        g32 = gamma.detach().float()
+        b32 = beta.detach().float()
+        if training:
+            L.bn_finalize(part.data_ptr(), nblk, Cout, M, g32.data_ptr(), b32.data_ptr(), m.eps, m.momentum,
+                          m.bn.running_mean.data_ptr(), m.bn.running_var.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                          stats[2].data_ptr(), stats[3].data_ptr(), st)
+            m._nbt_pending += 1
+        else:
+            L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), m.bn.running_mean.data_ptr(), m.bn.running_var.data_ptr(), m.eps,
+                            stats[2].data_ptr(), stats[3].data_ptr(), st)
+        z = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        rr = None
+        if res_mode:
+            rr = to_nhwc(res, dtype, dense=True)
+            assert rr.shape == z.shape, "residual shape mismatch"
+        L.bn_act_fwd(dt, y.data_ptr(), Cout, stats[2].data_ptr(), stats[3].data_ptr(), int(m.has_act), res_mode,
+                     rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), Cout, M, Cout, st)
+        ctx.m = m
+        ctx.cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype)
+        ctx.save_for_backward(xin, w32, y, stats, rr if res_mode == 2 else None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = lib()
+        xin, w32, y, stats, rr = ctx.saved_tensors
+        B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype = ctx.cfg
+        if not training:
+            raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
+        m = ctx.m
+        dt = code(dtype)
+        st = stream()
+        dev = dz.device
+        M = B * Ho * Wo
+        dz = to_nhwc(dz, dtype, dense=True)
+        nb = L.bn_bwd_blocks(M)
+        part = _f32(nb * Cout * 2, dev)
+        rptr = rr.data_ptr() if rr is not None else None
+        rsw = rr.stride(3) if rr is not None else 0
+        act = int(m.has_act)
+        L.bn_act_bwd_reduce(dt, y.data_ptr(), Cout, dz.data_ptr(), dz.stride(3), rptr, rsw, stats[2].data_ptr(), stats[3].data_ptr(),
+                            stats[0].data_ptr(), stats[1].data_ptr(), act, res_mode, part.data_ptr(), M, Cout, st)
+        dgb = _f32(2 * Cout, dev).view(2, Cout)
+        L.bn_bwd_finalize(part.data_ptr(), nb, Cout, M, dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stats[4].data_ptr(), stats[5].data_ptr(), st)
+        dy = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        dres = None
+        if res_mode == 2 and ctx.needs_input_grad[4]:
+            dres = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        L.bn_act_bwd_apply(dt, y.data_ptr(), Cout, dz.data_ptr(), dz.stride(3), rptr, rsw, stats[2].data_ptr(), stats[3].data_ptr(),
+                           stats[0].data_ptr(), stats[1].data_ptr(), stats[4].data_ptr(), stats[5].data_ptr(), act, res_mode, 1,
+                           dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
+        if res_mode == 1:
+            dres = dz
+        sb, sh, sw = s3(xin)
+        dx = None
+        dW = torch.empty_like(w32)
+        if dw:
+            wp = _f32(k * k * Cout, dev)
+            L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+            if ctx.needs_input_grad[0]:
+                dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+                dsb, dsh, dsw = s3(dy)
+                L.dwconv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wp.data_ptr(), dx.data_ptr(), Cin, H, W, k, k, s, p, st)
+            slab = _f32(L.dw_blocks(M) * k * k * Cout, dev)
+            L.dwconv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, dy.data_ptr(), Cout, Ho, Wo, k, k, s, p, slab.data_ptr(),
+                                  dW.data_ptr(), 0, st)
+        else:
+            if ctx.needs_input_grad[0] and Cin_k == Cin:
+                kp = L.conv_kpad(dt, k * k * (Cout // g))
+                wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
+                L.pack_weight_dgrad(dt, w32.data_ptr(), wpd.data_ptr(), Cout, Cin // g, g, k, k, st)
+                dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+                dsb, dsh, dsw = s3(dy)
+                L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, W, Cin, g, k, k, s, p, st)
+            ns = L.conv2d_wgrad_splits(dt, B, Ho, Wo, Cout, Cin_k // g, g, k, k)
+            slab = _f32(ns * Cout * k * k * (Cin_k // g), dev)
+            L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p,
+                                slab.data_ptr(), ns, dW.data_ptr(), 0, st)
+        return dx, dW, dgb[0], dgb[1], dres, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# plain nn.Conv2d(c, out, 1) with bias (head projections)
+# ------------------------------------------------------------------------------------------------------
+class HeadProjFn(torch.autograd.Function):
+    """cat_j( conv1x1_j(x_j) + b_j ) written straight into one (B, sum(out_j), H, W) NHWC tensor
+    (reference head.py:637 + the torch.cat of head.py:742).  args: n, x_0..x_{n-1}, w_0.., b_0.."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        L = lib()
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        dtype = _COMPUTE_DTYPE
+        dt = code(dtype)
+        st = stream()
+        B, _, H, W = xs[0].shape
+        P = B * H * W
+        couts = [w.shape[0] for w in ws]
+        tot = sum(couts)
+        out = nhwc_empty(B, tot, H, W, dtype, xs[0].device)
+        esz = out.element_size()
+        xs = [to_nhwc(x, dtype, dense=True) for x in xs]
+        w32 = [w.detach().float().contiguous() for w in ws]
+        b32 = [b.detach().float().contiguous() for b in bs]
+        off = 0
+        for x, w, b, co in zip(xs, w32, b32, couts):
+            for o0 in range(0, co, 24):
+                oc = min(24, co - o0)
+                L.proj_fwd(dt, x.data_ptr(), x.stride(3), w.data_ptr() + o0 * w.shape[1] * 4, b.data_ptr() + o0 * 4,
+                           out.data_ptr() + (off + o0) * esz, tot, P, x.shape[1], oc, st)
+            off += co
+        ctx.n, ctx.couts, ctx.dtype = n, couts, dtype
+        ctx.save_for_backward(*xs, *w32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = lib()
+        n, couts, dtype = ctx.n, ctx.couts, ctx.dtype
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dt = code(dtype)
+        st = stream()
+        if not (dout.dtype == dtype and px_dense(dout)):
+            dout = to_nhwc(dout, dtype, dense=True) if dout.shape[1] % ce(dtype) == 0 else _dense_any(dout, dtype)
+        B, tot, H, W = dout.shape
+        P = B * H * W
+        dev = dout.device
+        esz = dout.element_size()
+        dsw = dout.stride(3)
+        nb = L.proj_blocks(P)
+        dxs, dws, dbs = [], [], []
+        off = 0
+        for j, (x, w, co) in enumerate(zip(xs, ws, couts)):
+            Cin = x.shape[1]
+            dx = None
+            if ctx.needs_input_grad[1 + j]:
+                dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+                first = True
+                for o0 in range(0, co, 24):
+                    oc = min(24, co - o0)
+                    if first:
+                        L.proj_bwd_data(dt, dout.data_ptr() + (off + o0) * esz, dsw, w.data_ptr() + o0 * Cin * 4, dx.data_ptr(), Cin, P, Cin, oc, st)
+                        first = False
+                    else:
+                        tmp = nhwc_empty(B, Cin, H, W, dtype, dev)
+                        L.proj_bwd_data(dt, dout.data_ptr() + (off + o0) * esz, dsw, w.data_ptr() + o0 * Cin * 4, tmp.data_ptr(), Cin, P, Cin, oc, st)
+                        L.add2d(dt, dx.data_ptr(), Cin, tmp.data_ptr(), Cin, dx.data_ptr(), Cin, P, Cin, st)
+            dW = torch.empty_like(w)
+            db = _f32(co, dev)
+            slab = _f32(nb * co * Cin, dev)
+            bslab = _f32(nb * co, dev)
+            L.proj_bwd_weight(dt, x.data_ptr(), x.stride(3), dout.data_ptr() + off * esz, dsw, slab.data_ptr(), bslab.data_ptr(),
+                              dW.data_ptr(), db.data_ptr(), 0, P, Cin, co, st)
+            dxs.append(dx)
+            dws.append(dW)
+            dbs.append(db)
+            off += co
+        return (None, *dxs, *dws, *dbs)
+
+
+def _dense_any(x, dtype):
+    """pixel-dense NHWC copy without the 16-byte channel constraint (head maps with 38 / 144 channels)"""
+    B, C, H, W = x.shape
+    out = nhwc_empty(B, C, H, W, dtype, x.device)
+    out.copy_(x)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# graph glue
+# ------------------------------------------------------------------------------------------------------
+class ConcatFn(torch.autograd.Function):
+    """torch.cat(xs, 1) on NHWC tensors (Concat conv.py:404; C2f/SPPF/PSA cats). Backward returns channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        L = lib()
+        dtype = _COMPUTE_DTYPE
+        dt = code(dtype)
+        st = stream()
+        xs = [to_nhwc(x, dtype, dense=True) for x in xs]
+        B, _, H, W = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        tot = sum(cs)
+        out = nhwc_empty(B, tot, H, W, dtype, xs[0].device)
+        esz = out.element_size()
+        off = 0
+        for x, c in zip(xs, cs):
+            L.copy2d(dt, x.data_ptr(), x.stride(3), out.data_ptr() + off * esz, tot, B * H * W, c, st)
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(dout[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(k, 1, k//2) (SPPF block.py:171)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        L = lib()
+        dtype = _COMPUTE_DTYPE
+        dt = code(dtype)
+        x = to_nhwc(x, dtype)
+        B, C, H, W = x.shape
+        y = nhwc_empty(B, C, H, W, dtype, x.device)
+        need = x.requires_grad
+        arg = torch.empty(B * H * W * C, dtype=torch.uint8, device=x.device) if need else None
+        sb, sh, sw = s3(x)
+        L.maxpool_fwd(dt, x.data_ptr(), sb, sh, sw, y.data_ptr(), C, arg.data_ptr() if need else None, B, H, W, C, k, stream())
+        ctx.k = k
+        ctx.dtype = dtype
+        if need:
+            ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        (arg,) = ctx.saved_tensors
+        dtype = ctx.dtype
+        dy = to_nhwc(dy, dtype, dense=True)
+        B, C, H, W = dy.shape
+        dx = nhwc_empty(B, C, H, W, dtype, dy.device)
+        L.maxpool_bwd(code(dtype), dy.data_ptr(), dy.stride(3), arg.data_ptr(), dx.data_ptr(), C, B, H, W, C, ctx.k, stream())
+        return dx, None
+
+
+class Upsample2xFn(torch.autograd.Function):
+    """nn.Upsample(None, 2, 'nearest')"""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = lib()
+        dtype = _COMPUTE_DTYPE
+        x = to_nhwc(x, dtype)
+        B, C, H, W = x.shape
+        y = nhwc_empty(B, C, 2 * H, 2 * W, dtype, x.device)
+        sb, sh, sw = s3(x)
+        L.upsample2x_fwd(code(dtype), x.data_ptr(), sb, sh, sw, y.data_ptr(), C, B, H, W, C, stream())
+        ctx.dtype = dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        dtype = ctx.dtype
+        dy = to_nhwc(dy, dtype)
+        B, C, H2, W2 = dy.shape
+        dx = nhwc_empty(B, C, H2 // 2, W2 // 2, dtype, dy.device)
+        sb, sh, sw = s3(dy)
+        L.upsample2x_bwd(code(dtype), dy.data_ptr(), sb, sh, sw, dx.data_ptr(), C, B, H2 // 2, W2 // 2, C, stream())
+        return dx
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q^T k * scale) applied to v, per head, on the NHWC qkv tensor; also returns v re-laid-out as
+    (B, nh*hd, H, W) for the `pe` branch (reference block.py:785-797)."""
+
+    @staticmethod
+    def forward(ctx, qkv, nh, kd, hd, scale):
+        L = lib()
+        dtype = _COMPUTE_DTYPE
+        dt = code(dtype)
+        st = stream()
+        qkv = to_nhwc(qkv, dtype, dense=True)
+        B, Ct, H, W = qkv.shape
+        N = H * W
+        C = nh * hd
+        dev = qkv.device
+        out = nhwc_empty(B, C, H, W, dtype, dev)
+        v = nhwc_empty(B, C, H, W, dtype, dev)
+        lse = _f32(B * nh * N, dev)
+        L.attn_fwd(dt, qkv.data_ptr(), qkv.stride(3), out.data_ptr(), C, lse.data_ptr(), B, N, nh, kd, hd, scale, st)
+        esz = qkv.element_size()
+        for h in range(nh):
+            L.copy2d(dt, qkv.data_ptr() + (h * (2 * kd + hd) + 2 * kd) * esz, qkv.stride(3), v.data_ptr() + h * hd * esz, C, B * N, hd, st)
+        ctx.cfg = (nh, kd, hd, scale, dtype)
+        ctx.save_for_backward(qkv, out, lse)
+        return out, v
+
+    @staticmethod
+    def backward(ctx, dout, dv):
+        L = lib()
+        qkv, out, lse = ctx.saved_tensors
+        nh, kd, hd, scale, dtype = ctx.cfg
+        dt = code(dtype)
+        B, Ct, H, W = qkv.shape
+        N = H * W
+        C = nh * hd
+        dev = qkv.device
+        if dout is None:
+            dout = torch.zeros_like(out)
+        dout = to_nhwc(dout, dtype, dense=True)
+        dvp, dvs = None, 0
+        if dv is not None:
+            dv = to_nhwc(dv, dtype, dense=True)
+            dvp, dvs = dv.data_ptr(), dv.stride(3)
+        dqkv = nhwc_empty(B, Ct, H, W, dtype, dev)
+        delta = _f32(B * nh * N, dev)
+        L.attn_bwd(dt, qkv.data_ptr(), qkv.stride(3), out.data_ptr(), C, dout.data_ptr(), dout.stride(3), dvp, dvs, lse.data_ptr(),
+                   delta.data_ptr(), dqkv.data_ptr(), Ct, B, N, nh, kd, hd, scale, stream())
+        return dqkv, None, None, None, None

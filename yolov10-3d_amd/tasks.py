@@ -1,0 +1,214 @@
+"""yaml table -> model, and the model-level call convention of the reference
+(ultralytics/nn/tasks.py: BaseModel :80-280, DetectionModel :283-318, YOLOv10DetectionModel :645,
+YOLOv10_3DDetectionModel :649, parse_model :837-964, yaml_model_load :967).
+
+Same yaml schema, same `model.{i}.…` state_dict keys, same `model(batch_dict) -> (loss*B, items)` /
+`model(img) -> preds` dispatch.  Differences, all deliberate:
+  * strides are derived from the table instead of probing a 256x256 CPU forward (the modules only run on HIP);
+  * `kernel_size_1/2` default to 3 when a 3D yaml omits them (the reference raises TypeError there).
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+import os
+import re
+from copy import deepcopy
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import modules as M
+from .modules import (C2f, C2fCIB, Concat, Conv, Detect, DWConv, PSA, SCDown, SPPF, Upsample, v10Detect, v10Detect3d)
+
+CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg", "models")
+
+# hyper-parameters the losses read (reference cfg/default.yaml:102-141), with the offline-only pins of SURVEY §0.5
+DEFAULT_HYP = dict(box=5.0, cls=1.0, dfl=1.5, loss2d=2.0, depth=1.0, offset3d=10.0, size3d=1.0, heading=1.0,
+                   tal_topk=8, tal_alpha=0.5, tal_beta=1.0, tal_gamma=1.0, tal_3d=True, tal_2d=True, kps_dist_metric="l1",
+                   constrain_anchors=True, distillation=False, fgdm_loss=False, fgdm_supervision=False, htl=False)
+
+_REGISTRY = {"Conv": Conv, "DWConv": DWConv, "C2f": C2f, "C2fCIB": C2fCIB, "SCDown": SCDown, "SPPF": SPPF, "PSA": PSA,
+             "Concat": Concat, "nn.Upsample": Upsample, "Detect": Detect, "v10Detect": v10Detect, "v10Detect3d": v10Detect3d}
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def guess_model_scale(path):
+    with contextlib.suppress(AttributeError):
+        return re.search(r"yolov\d+([nsblmx])", os.path.splitext(os.path.basename(str(path)))[0]).group(1)
+    return ""
+
+
+def yaml_model_load(path):
+    """reference tasks.py:967-985; bare names resolve inside the package's cfg/models tree"""
+    p = str(path)
+    if not os.path.exists(p):
+        for sub in ("v10-3D", "v10", ""):
+            q = os.path.join(CFG_DIR, sub, os.path.basename(p))
+            if os.path.exists(q):
+                p = q
+                break
+    with open(p) as f:
+        d = yaml.safe_load(f)
+    d["scale"] = guess_model_scale(p)
+    d["yaml_file"] = p
+    return d
+
+
+def parse_model(d, ch, verbose=False):
+    """reference tasks.py:837-964 for the module set of the v10 / v10-3D tables"""
+    max_channels = float("inf")
+    nc, scales = d.get("nc"), d.get("scales")
+    depth, width = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0)
+    if scales:
+        scale = d.get("scale") or tuple(scales.keys())[0]
+        depth, width, max_channels = scales[scale]
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        if m not in _REGISTRY:
+            raise NotImplementedError(f"module '{m}' is outside the YOLOv10 / YOLOv10-3D path")
+        mod = _REGISTRY[m]
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                args[j] = nc if a == "nc" else (None if a == "None" else a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        if mod in (Conv, DWConv, C2f, C2fCIB, SCDown, SPPF, PSA):
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if mod in (C2f, C2fCIB):
+                args.insert(2, n)
+                n = 1
+        elif mod is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif mod in (Detect, v10Detect, v10Detect3d):
+            args.append([ch[x] for x in f])
+            if mod is v10Detect3d:
+                for key in ("dsconv", "channels", "use_predecessors", "detach_predecessors", "deform", "common_head", "num_scales",
+                            "half_channels", "fgdm_predictor", "kernel_size_1", "kernel_size_2"):
+                    args.append(d.get(key))
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*(mod(*args) for _ in range(n))) if n > 1 else mod(*args)
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, m
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+def table_strides(model: nn.Sequential, nl=None):
+    """down-sampling factor of each detect input, derived from the layer table"""
+    down = {}
+    for m in model:
+        f = m.f
+        src = 1 if m.i == 0 else down[(f if f >= 0 else m.i + f)] if isinstance(f, int) else None
+        if isinstance(m, (Detect, v10Detect3d)):
+            out = [float(down[x]) for x in f]
+            return out[:nl] if nl else out
+        if isinstance(m, Conv):
+            cur = src * m.s
+        elif isinstance(m, SCDown):
+            cur = src * m.cv2.s
+        elif isinstance(m, Upsample):
+            cur = src / 2
+        elif isinstance(m, Concat):
+            cur = down[f[0] if f[0] >= 0 else m.i + f[0]]
+        else:
+            cur = src
+        down[m.i] = cur
+    raise ValueError("no detect layer in the table")
+
+
+def initialize_weights(model):
+    """reference utils/torch_utils.py:327-337"""
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps = 1e-3
+            m.momentum = 0.03
+        elif isinstance(m, (nn.SiLU,)):
+            m.inplace = True
+
+
+class BaseModel(nn.Module):
+    """reference tasks.py:80-280"""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            return self.loss(x, *args, **kwargs)
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        return self._predict_once(x)
+
+    def _predict_once(self, x):
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def loss(self, batch, preds=None):
+        if not hasattr(self, "criterion"):
+            self.criterion = self.init_criterion()
+        preds = self.forward(batch["img"]) if preds is None else preds
+        return self.criterion(preds, batch)
+
+    def init_criterion(self):
+        raise NotImplementedError
+
+    def load(self, weights, verbose=False):
+        """reference tasks.py:249-262: transfer by intersecting state_dict keys/shapes"""
+        sd = weights if isinstance(weights, dict) else weights.state_dict()
+        own = self.state_dict()
+        ok = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        self.load_state_dict(ok, strict=False)
+        return len(ok), len(own)
+
+
+class DetectionModel(BaseModel):
+    """reference tasks.py:283-318"""
+
+    def __init__(self, cfg="yolov10s_3D.yaml", ch=3, nc=None, verbose=False):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        m = self.model[-1]
+        if isinstance(m, (Detect, v10Detect3d)):
+            m.stride = torch.tensor(table_strides(self.model, m.nl))
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        initialize_weights(self)
+        self.args = SimpleNamespace(**DEFAULT_HYP)
+
+
+class YOLOv10DetectionModel(DetectionModel):
+    def init_criterion(self):
+        from .loss import v10DetectLoss
+        return v10DetectLoss(self)
+
+
+class YOLOv10_3DDetectionModel(DetectionModel):
+    def init_criterion(self):
+        from .loss import DetectLoss3d
+        return DetectLoss3d(self)
