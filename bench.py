@@ -1,0 +1,255 @@
+"""bench.py — images/sec of the YOLOv10-S-3D 640x640 hot path on N MI355X (one process per GPU, RCCL over xGMI).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one training pass of the hot path over one synthetic batch that is already resident in HBM:
+forward (backbone + neck + PSA + dual 3D head) + dual-assignment loss + backward + gradient clip + optimizer
+step.  Workload = BASELINE.json configs[1]: YOLOv10-S + 3D head, 640x640, bf16, batch 32 per GPU (weak scaling:
+the reference's image-parallel DDP, trainer.py:292).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     — dominant kernel (3x3 128->128 @80x80 implicit-GEMM conv forward, 54 % of the step's FLOPs),
+                 timed live with HIP events on the launch stream during the timed region; algorithmic FLOPs
+                 2*B*Ho*Wo*Cout*Cin*9 per launch against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline — the CPU oracle restatement (oracle/restate.py, fp32, all host cores) on a bounded sample of the same
+                 workload (B=2 steps), kind "port".  A reported baseline, never the product path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def synth_batch(B, H, W, seed, device, nc=3):
+    """SURVEY §8d synthetic recipe: n ~ U{1..8} boxes per image, KITTI-like calibration and mean sizes."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, H, W, generator=g)
+    counts = torch.randint(1, 9, (B,), generator=g)
+    bi = torch.repeat_interleave(torch.arange(B), counts).float()
+    n = int(counts.sum())
+    cxy = 0.2 + 0.6 * torch.rand(n, 2, generator=g)
+    wh = 0.05 + 0.25 * torch.rand(n, 2, generator=g)
+    scale = torch.tensor([W, H], dtype=torch.float32)
+    c2 = cxy * scale
+    batch = {
+        "img": img, "batch_idx": bi, "cls": torch.randint(0, nc, (n, 1), generator=g).float(), "bboxes": torch.cat((cxy, wh), 1),
+        "center_2d": c2, "size_2d": wh * scale, "center_3d": c2 + 2.0 * torch.randn(n, 2, generator=g),
+        "size_3d": 0.1 * torch.randn(n, 3, generator=g), "depth": 5 + 55 * torch.rand(n, generator=g),
+        "heading_bin": torch.randint(0, 12, (n,), generator=g).float(), "heading_res": (torch.rand(n, generator=g) - 0.5) * (math.pi / 6),
+        "calib": torch.tensor([[W / 2, H / 2, 700.0, 700.0, 0.06, -0.002]]).repeat(B, 1),
+        "mean_sizes": torch.tensor([[1.76255119, 0.66068622, 0.84422524], [1.52563191, 1.62856739, 3.88311640],
+                                    [1.73698127, 0.59706367, 1.76282397]]),
+    }
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
+    """reference engine/trainer.py:734-790: three parameter groups (weights with decay, BN weights, biases), SGD nesterov"""
+    g = [], [], []
+    bn = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k)
+    seen = set()
+    for mod in model.modules():
+        for pn, p in mod.named_parameters(recurse=False):
+            if id(p) in seen or not p.requires_grad:
+                continue
+            seen.add(id(p))
+            if pn == "bias":
+                g[2].append(p)
+            elif isinstance(mod, bn):
+                g[1].append(p)
+            else:
+                g[0].append(p)
+    opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
+    opt.add_param_group({"params": g[0], "weight_decay": decay})
+    opt.add_param_group({"params": g[1], "weight_decay": 0.0})
+    return opt
+
+
+def cpu_baseline(model_name, imgsz, seed, steps=2, B=2):
+    """oracle restatement (fp32) timed on the host cores: fwd + loss + bwd on a bounded sample (B=2 per step)."""
+    import yaml
+
+    from oracle import restate as RS
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box gives one GPU's CPU share (16 cores); more threads only oversubscribe
+    torch.set_num_threads(cores)
+    with open(os.path.join(ROOT, "yolov10-3d_amd", "cfg", "models", "v10-3D", model_name)) as f:
+        cfg = yaml.safe_load(f)
+    cfg["scale"] = RS.guess_scale(model_name)
+    spec = RS.build_spec(cfg)
+    st = RS.init_state(spec, seed=0, randomize_bn=False)
+    params = [v.requires_grad_(True) for k, v in st.items() if v.is_floating_point() and "running" not in k]
+    batch = synth_batch(B, imgsz, imgsz, seed, "cpu")
+    strides = RS.model_strides(spec)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        preds = RS.forward(spec, st, batch["img"], True)
+        loss, items, _ = RS.loss3d(preds, batch, strides, 3)
+        loss.backward()
+        for p in params:
+            p.grad = None
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": B / t, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/restate.py fp32 train step (fwd+loss+bwd), {model_name} {imgsz}x{imgsz}, B={B}, median of {steps} steps after 1 warm-up"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--model", default="yolov10s_3D.yaml")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--infer-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import yolov10_3d_amd as y3d
+    from yolov10_3d_amd import ops
+    from yolov10_3d_amd.loss import v10_3Dpostprocess
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    y3d.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    model = y3d.YOLOv10_3DDetectionModel(args.model).to(dev).train()
+    opt = build_optimizer(model)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
+    B, S = args.batch, args.imgsz
+    batch = synth_batch(B, S, S, seed=1 + rank, device=dev)  # resident in HBM before the timed region
+
+    def step():
+        loss, items = net(batch)
+        if world > 1:
+            loss = loss * world  # reference trainer.py:401-402 (DDP averages gradients)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)  # trainer.py:570
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return items
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log(f"model {args.model} built, {sum(p.numel() for p in model.parameters()) / 1e6:.2f} M params; warm-up {args.warmup} steps")
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        items = step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {1e3 * (time.perf_counter() - tw):.1f} ms, loss items {[round(float(v), 3) for v in items.float().cpu()]}")
+    # headline kernel: 3x3 s1 conv forward Cin=Cout=128 on the 80x80 (stride-8) map
+    P3 = S // 8
+    dt_code = 1 if dtype == torch.bfloat16 else 0
+    k1_key = ("conv_fwd", dt_code, B, P3, P3, 128, 128, 3, 1, 1)
+    ops.TIMER = ops.KernelTimer(lambda key: key == k1_key)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items = step()
+    sync()
+    dt_s = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    tmax = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_s = float(tmax)
+    log(f"timed {args.steps} steps: {1e3 * dt_s / args.steps:.2f} ms/step")
+    assert torch.isfinite(items).all(), f"non-finite loss items {items}"
+    train_ips = world * B * args.steps / dt_s
+
+    # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190)
+    model.eval()
+    infer_ips = None
+    with torch.no_grad():
+        for _ in range(2):
+            y = model(batch["img"])["one2one"][0]
+            v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.infer_steps):
+            y = model(batch["img"])["one2one"][0]
+            v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
+        sync()
+        ti = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+        infer_ips = world * B * args.infer_steps / float(ti)
+    log(f"infer: {infer_ips:.1f} images/s")
+
+    if rank == 0:
+        res = timer.results().get(k1_key, [])
+        roof = None
+        if res:
+            avg_ms = sum(res) / len(res)
+            flops = 2.0 * B * P3 * P3 * 128 * 128 * 9
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<bf16,128,128,2,2,fwd> 3x3 s1 128->128 @%dx%d B=%d" % (P3, P3, B),
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
+        cpu = None
+        if not args.no_cpu_baseline:
+            log("cpu baseline (oracle restatement on the host cores) ...")
+            cpu = cpu_baseline(args.model, S, seed=1)
+            log(f"cpu baseline: {cpu['value']:.3f} images/s on {cpu['cores']} cores")
+        out = {
+            "metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"YOLOv10-S + 3D head ({args.model}), {S}x{S}, {args.dtype}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD",
+                       "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
+            "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None,
+            "loss_items": [round(float(v), 5) for v in items.float().cpu()],
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

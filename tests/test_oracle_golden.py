@@ -228,7 +228,7 @@ def test_e2e_tiny3d(tag, over):
     for k, v in g["state_after"].items():
         close(st[k].detach(), v)
     st2 = {k: v.clone() for k, v in g["state"].items()}
-    st2.update({k: v.clone() for k, v in g["state_after"].items()})  # eval pass of the fixture ran after the train step
+    st2.update({k: v.clone() for k, v in g["state_eval"].items()})  # running stats the fixture's eval pass saw
     with torch.no_grad():
         y = RS.forward(spec, st2, g["img_eval"], False)["one2one"][0]
     close(y, g["y_eval"], rtol=1e-3, atol=1e-3)

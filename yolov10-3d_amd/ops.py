@@ -85,6 +85,35 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+class KernelTimer:
+    """Live per-launch timing of selected kernels with HIP events on the launch stream (bench.py's roofline leg).
+    `want(key)` decides which launches are bracketed; results: {key: [ms, ...]}."""
+
+    def __init__(self, want):
+        self.want = want
+        self.pending = []
+
+    def bracket(self, key, fn):
+        if not self.want(key):
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.pending.append((key, a, b))
+        return r
+
+    def results(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, a, b in self.pending:
+            out.setdefault(key, []).append(a.elapsed_time(b))
+        return out
+
+
+TIMER = None  # set by bench.py
+
+
 # ------------------------------------------------------------------------------------------------------
 # Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
 # ------------------------------------------------------------------------------------------------------
@@ -144,8 +173,12 @@ class ConvBNActFn(torch.autograd.Function):
             Cg_pad = Cin_k // g
             wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
             L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
-            L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
-                         k, k, s, p, part.data_ptr() if training else None, st)
+            launch = lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo,
+                                          Cout, g, k, k, s, p, part.data_ptr() if training else None, st)
+            if TIMER is not None:
+                TIMER.bracket(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g), launch)
+            else:
+                launch()
         stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
         g32 = gamma.detach().float()
         b32 = beta.detach().float()
@@ -220,11 +253,20 @@ class ConvBNActFn(torch.autograd.Function):
                 L.pack_weight_dgrad(dt, w32.data_ptr(), wpd.data_ptr(), Cout, Cin // g, g, k, k, st)
                 dx = nhwc_empty(B, Cin, H, W, dtype, dev)
                 dsb, dsh, dsw = s3(dy)
-                L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, W, Cin, g, k, k, s, p, st)
+                launch = lambda: L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, W,
+                                                   Cin, g, k, k, s, p, st)
+                if TIMER is not None:
+                    TIMER.bracket(("conv_dgrad", dt, B, H, W, Cin, Cout, k, s, g), launch)
+                else:
+                    launch()
             ns = L.conv2d_wgrad_splits(dt, B, Ho, Wo, Cout, Cin_k // g, g, k, k)
             slab = _f32(ns * Cout * k * k * (Cin_k // g), dev)
-            L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p,
-                                slab.data_ptr(), ns, dW.data_ptr(), 0, st)
+            launch = lambda: L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k,
+                                                 s, p, slab.data_ptr(), ns, dW.data_ptr(), 0, st)
+            if TIMER is not None:
+                TIMER.bracket(("conv_wgrad", dt, B, H, W, Cin_k, Cout, k, s, g), launch)
+            else:
+                launch()
         return dx, dW, dgb[0], dgb[1], dres, None, None
 
 
