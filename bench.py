@@ -181,10 +181,12 @@ def main():
         items = step()
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - tw):.1f} ms, loss items {[round(float(v), 3) for v in items.float().cpu()]}")
-    # headline kernel: 3x3 s1 conv forward Cin=Cout=128 on the 80x80 (stride-8) map
+    # headline kernel: the 3x3 s1 128->128 conv forward on the 80x80 (stride-8) map — SURVEY §0.4's 54 %-of-FLOPs shape.  The
+    # 16 sibling instances (8 branches x 2 head sets, second conv of each) run as ONE grouped launch: 16 groups of 128->128.
     P3 = S // 8
     dt_code = 1 if dtype == torch.bfloat16 else 0
-    k1_key = ("conv_fwd", dt_code, B, P3, P3, 128, 128, 3, 1, 1)
+    mid = model.model[-1].o2o_heads[0][0][1].conv.in_channels
+    k1_key = ("conv_fwd", dt_code, B, P3, P3, 16 * mid, 16 * mid, 3, 1, 16)
     ops.TIMER = ops.KernelTimer(lambda key: key == k1_key)
     sync()
     t0 = time.perf_counter()
@@ -225,10 +227,10 @@ def main():
         roof = None
         if res:
             avg_ms = sum(res) / len(res)
-            flops = 2.0 * B * P3 * P3 * 128 * 128 * 9
+            flops = 2.0 * B * P3 * P3 * 16 * mid * mid * 9
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
-            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<bf16,128,128,2,2,fwd> 3x3 s1 128->128 @%dx%d B=%d" % (P3, P3, B),
+            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s,128,128,2,2,fwd> 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None

@@ -15,20 +15,22 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
                                    float* __restrict__ run_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  __shared__ double sh[4][64][2];
-  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  int c = blockIdx.x * 64 + cx;
+  // 8 channels x 32 row-threads per block: the partial slab has up to ceil(B*H*W/128) rows
+  __shared__ double sh[32][8][2];
+  int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  int c = blockIdx.x * 8 + cx;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int b = ry; b < nblk; b += 4) {
-      s += (double)part[((long)b * C + c) * 2];
-      q += (double)part[((long)b * C + c) * 2 + 1];
+    for (int b = ry; b < nblk; b += 32) {
+      float2 v = *(const float2*)(part + ((long)b * C + c) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
     }
   sh[ry][cx][0] = s;
   sh[ry][cx][1] = q;
   __syncthreads();
   if (ry == 0 && c < C) {
-    for (int r = 1; r < 4; ++r) { s += sh[r][cx][0]; q += sh[r][cx][1]; }
+    for (int r = 1; r < 32; ++r) { s += sh[r][cx][0]; q += sh[r][cx][1]; }
     double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -139,20 +141,21 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, cons
 // partial[nblk][C][2] -> dgamma (sum g*xhat), dbeta (sum g), and the two per-channel means used by pass 2
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int accumulate, float* __restrict__ mg, float* __restrict__ mgx) {
-  __shared__ double sh[4][64][2];
-  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  int c = blockIdx.x * 64 + cx;
+  __shared__ double sh[32][8][2];
+  int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  int c = blockIdx.x * 8 + cx;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int b = ry; b < nblk; b += 4) {
-      s += (double)part[((long)b * C + c) * 2];
-      q += (double)part[((long)b * C + c) * 2 + 1];
+    for (int b = ry; b < nblk; b += 32) {
+      float2 v = *(const float2*)(part + ((long)b * C + c) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
     }
   sh[ry][cx][0] = s;
   sh[ry][cx][1] = q;
   __syncthreads();
   if (ry == 0 && c < C) {
-    for (int r = 1; r < 4; ++r) { s += sh[r][cx][0]; q += sh[r][cx][1]; }
+    for (int r = 1; r < 32; ++r) { s += sh[r][cx][0]; q += sh[r][cx][1]; }
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
     mg[c] = (float)(s / count);
@@ -246,7 +249,7 @@ int y3d_bn_finalize(const float* partials, int nblk, int C, int64_t count, const
                     float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                     float* shift, void* stream) {
   Y3D_CHECK(nblk > 0 && C > 0 && count > 0, "bn_finalize: empty");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, (double)count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, (double)count,
                      gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
@@ -282,7 +285,7 @@ int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, co
 
 int y3d_bn_bwd_blocks(int64_t P) {
   long n = (P + 511) / 512;
-  return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+  return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
 }
 
 #define BWD_REDUCE(T, A, R)                                                                                                  \
@@ -312,7 +315,7 @@ int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz,
 
 int y3d_bn_bwd_finalize(const float* partials, int nblk, int C, int64_t count, float* dgamma, float* dbeta, int accumulate,
                         float* mean_g, float* mean_gx, void* stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
                      (double)count, dgamma, dbeta, accumulate, mean_g, mean_gx);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;

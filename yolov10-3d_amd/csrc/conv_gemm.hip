@@ -30,6 +30,7 @@ struct ConvP {
   int kh, kw, stride, pad;
   int Ktot, Kpad;  // taps*Cg and its padding to a chunk multiple (row pitch of packed weights)
   int M;           // B*Hq*Wq
+  int ntx, nty;    // tile grid (pixel tiles x channel tiles); the launch is 1-D over ntx*nty, remapped per XCD
 };
 
 template <typename T> struct Frag;
@@ -79,32 +80,67 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
   const int wave = tid >> 6;
   const int wp = wave / WC, wc = wave % WC;
   const int g = blockIdx.z;
-  const int p0 = blockIdx.x * BP;
-  const int c0 = blockIdx.y * BC;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of tiles and
+  // walk the channel tiles of one pixel tile back to back: the blocks that re-read the same input pixels share one L2.
+  int tile_x, tile_y;
+  {
+    const int nwg = p.ntx * p.nty, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_y = lin % p.nty;
+    tile_x = lin / p.nty;
+  }
+  const int p0 = tile_x * BP;
+  const int c0 = tile_y * BC;
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ Wt = (const T*)p.w;
 
   // ---- loader state: this thread owns chunk column cc of rows (tid>>3) + 32*i -------------------
+  // Per row: a base pointer and a bit mask of the filter taps that land inside the gathered tensor, both computed once.
+  // Per K step the address is base + (tap offset + channel), i.e. one 64-bit add and one mask test per 16-byte chunk.
   const int cc = tid & 7;
   const int r0 = tid >> 3;
-  long abase[RA];
-  int ah[RA], aw[RA];
+  const long SH = DGRAD ? p.xsh / p.stride : p.xsh;  // dgrad: (t/s)*xsh == t*(xsh/s) for the taps the mask admits
+  const long SW = DGRAD ? p.xsw / p.stride : p.xsw;
+  const T* aptr[RA];
+  unsigned long long amask[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     int m = p0 + r0 + 32 * i;
+    aptr[i] = X;
+    amask[i] = 0ull;
     if (m < p.M) {
       int b = m / (p.Hq * p.Wq);
       int rem = m - b * (p.Hq * p.Wq);
       int hq = rem / p.Wq;
       int wq = rem - hq * p.Wq;
-      abase[i] = (long)b * p.xsb + (long)g * p.Cg;
-      if (DGRAD) { ah[i] = hq + p.pad; aw[i] = wq + p.pad; }
-      else { ah[i] = hq * p.stride - p.pad; aw[i] = wq * p.stride - p.pad; }
-    } else {
-      abase[i] = -1; ah[i] = 0; aw[i] = 0;
+      int a_h = DGRAD ? hq + p.pad : hq * p.stride - p.pad;
+      int a_w = DGRAD ? wq + p.pad : wq * p.stride - p.pad;
+      aptr[i] = X + (long)b * p.xsb + (long)g * p.Cg + (long)a_h * SH + (long)a_w * SW;
+      unsigned long long mk = 0ull;
+      for (int r = 0; r < p.kh; ++r)
+        for (int q = 0; q < p.kw; ++q) {
+          bool ok;
+          if (DGRAD) {
+            int th = a_h - r, tw = a_w - q;
+            int hh = th / p.stride, ww = tw / p.stride;
+            ok = th >= 0 && tw >= 0 && hh * p.stride == th && ww * p.stride == tw && hh < p.Hg && ww < p.Wg;
+          } else {
+            int hh = a_h + r, ww = a_w + q;
+            ok = hh >= 0 && ww >= 0 && hh < p.Hg && ww < p.Wg;
+          }
+          if (ok) mk |= 1ull << (r * p.kw + q);
+        }
+      amask[i] = mk;
     }
   }
-  // K position of this thread's chunk: k = kt*BKE + cc*CE -> (tap r,q ; channel ci)
+  const T* bptr[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = c0 + r0 + 32 * i;
+    bptr[i] = n < p.Cn ? Wt + ((long)(g * p.Cn + n)) * p.Kpad + cc * CE : nullptr;
+  }
+  // K position of this thread's chunk: k = kt*BKE + cc*CE -> (tap index, channel ci)
   int kpos = cc * CE;
   int kci = kpos % p.Cg;
   int ktap = kpos / p.Cg;
@@ -115,32 +151,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
 
   auto gload = [&](int kt) {
     const bool kvalid = kpos < p.Ktot;
+    const long koff = (DGRAD ? -((long)kr * SH + (long)kq * SW) : ((long)kr * SH + (long)kq * SW)) + kci;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (kvalid && abase[i] >= 0) {
-        int hh, ww;
-        bool ok;
-        if (DGRAD) {
-          int th = ah[i] - kr, tw = aw[i] - kq;
-          if (p.stride == 1) { hh = th; ww = tw; ok = th >= 0 && tw >= 0; }
-          else {
-            hh = th / p.stride; ww = tw / p.stride;
-            ok = th >= 0 && tw >= 0 && hh * p.stride == th && ww * p.stride == tw;
-          }
-        } else {
-          hh = ah[i] + kr; ww = aw[i] + kq;
-          ok = hh >= 0 && ww >= 0;
-        }
-        if (ok && hh < p.Hg && ww < p.Wg) v = *(const uint4*)(X + abase[i] + (long)hh * p.xsh + (long)ww * p.xsw + kci);
-      }
+      if (kvalid && ((amask[i] >> ktap) & 1ull)) v = *(const uint4*)(aptr[i] + koff);
       ra[i] = v;
     }
+    const bool wvalid = kpos < p.Kpad;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      int n = c0 + r0 + 32 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < p.Cn && kpos < p.Kpad) v = *(const uint4*)(Wt + ((long)(g * p.Cn + n)) * p.Kpad + kpos);
+      if (wvalid && bptr[i]) v = *(const uint4*)(bptr[i] + (long)kt * BKE);
       rb[i] = v;
     }
     // advance to the next K step
@@ -148,9 +170,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
     kci += BKE;
     while (kci >= p.Cg) {
       kci -= p.Cg;
+      ++ktap;
       if (++kq == p.kw) { kq = 0; ++kr; }
     }
-    (void)kt;
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -261,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WP; ++w) { s += red[(w * BC + tid) * 2]; q += red[(w * BC + tid) * 2 + 1]; }
-      float* dst = p.part + ((long)blockIdx.x * (p.G * p.Cn) + g * p.Cn + c0 + tid) * 2;
+      float* dst = p.part + ((long)tile_x * (p.G * p.Cn) + g * p.Cn + c0 + tid) * 2;
       dst[0] = s;
       dst[1] = q;
     }
@@ -354,25 +376,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int HW = p.Ho * p.Wo;
 
   uint4 rd[NCH], rx[NCH];
+  // per-row pixel coordinates, decoded once and advanced by BPK pixels per step (no divisions in the loop)
+  int rb_[NCH], rh_[NCH], rw_[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int m = mbeg + rr0 + RSTEP * i;
+    int b = m / HW;
+    int rem = m - b * HW;
+    rb_[i] = b;
+    rh_[i] = rem / p.Wo;
+    rw_[i] = rem - rh_[i] * p.Wo;
+  }
+  const T* dcol = D + (long)g * p.Cn + cd;
+  const T* xcol = X + (long)g * p.Cg + ci + (long)(tr - p.pad) * p.xsh + (long)(tq - p.pad) * p.xsw;
   auto gload = [&](int st) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int m = mbeg + st * BPK + rr0 + RSTEP * i;
       uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
       if (m < mend) {
-        if (cd_ok) vd = *(const uint4*)(D + (long)m * p.dsw + (long)g * p.Cn + cd);
+        if (cd_ok) vd = *(const uint4*)(dcol + (long)m * p.dsw);
         if (kx_ok) {
-          int b = m / HW;
-          int rem = m - b * HW;
-          int ho = rem / p.Wo;
-          int wo = rem - ho * p.Wo;
-          int hh = ho * p.stride - p.pad + tr, ww = wo * p.stride - p.pad + tq;
+          int hh = rh_[i] * p.stride - p.pad + tr, ww = rw_[i] * p.stride - p.pad + tq;
           if (hh >= 0 && ww >= 0 && hh < p.H && ww < p.W)
-            vx = *(const uint4*)(X + (long)b * p.xsb + (long)hh * p.xsh + (long)ww * p.xsw + (long)g * p.Cg + ci);
+            vx = *(const uint4*)(xcol + (long)rb_[i] * p.xsb + (long)(rh_[i] * p.stride) * p.xsh + (long)(rw_[i] * p.stride) * p.xsw);
         }
       }
       rd[i] = vd;
       rx[i] = vx;
+      rw_[i] += BPK;
+      while (rw_[i] >= p.Wo) { rw_[i] -= p.Wo; ++rh_[i]; }
+      while (rh_[i] >= p.Ho) { rh_[i] -= p.Ho; ++rb_[i]; }
     }
   };
   auto lstore = [&](int buf) {
@@ -480,20 +514,21 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__
 }
 
 template <typename T, bool DGRAD>
-int launch_conv(const ConvP& p, hipStream_t st) {
+int launch_conv(ConvP p, hipStream_t st) {
   dim3 block(256);
+  p.ntx = cdiv(p.M, 128);
   if (p.Cn > 64) {
-    dim3 grid(cdiv(p.M, 128), cdiv(p.Cn, 128), p.G);
+    p.nty = cdiv(p.Cn, 128);
     size_t sm = 2 * (128 + 128) * 128;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2, DGRAD>), grid, block, sm, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2, DGRAD>), dim3(p.ntx * p.nty, 1, p.G), block, sm, st, p);
   } else if (p.Cn > 32) {
-    dim3 grid(cdiv(p.M, 128), 1, p.G);
+    p.nty = 1;
     size_t sm = 2 * (128 + 64) * 128;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 4, 1, DGRAD>), grid, block, sm, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 4, 1, DGRAD>), dim3(p.ntx, 1, p.G), block, sm, st, p);
   } else {
-    dim3 grid(cdiv(p.M, 128), 1, p.G);
+    p.nty = 1;
     size_t sm = 2 * (128 + 32) * 128;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1, DGRAD>), grid, block, sm, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1, DGRAD>), dim3(p.ntx, 1, p.G), block, sm, st, p);
   }
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
@@ -554,6 +589,7 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
   Y3D_CHECK((Cin / groups) % ce == 0, "conv2d_fwd: Cin/groups=%d must be a multiple of %d (pad the input)", Cin / groups, ce);
   Y3D_CHECK(Ho == (H + 2 * pad - kh) / stride + 1 && Wo == (W + 2 * pad - kw) / stride + 1, "conv2d_fwd: output dims (%d,%d) inconsistent", Ho, Wo);
   Y3D_CHECK(ysw >= Cout, "conv2d_fwd: ysw < Cout");
+  Y3D_CHECK(kh * kw <= 64, "conv2d_fwd: at most 64 filter taps");
   Y3D_CHECK(!(bias && stat_partials), "conv2d_fwd: bias and BN partials are mutually exclusive");
   if (check_align("conv2d_fwd x", x, xsb, xsh, xsw, ce)) return Y3D_ERR_INVALID;
   Y3D_CHECK(((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 7) == 0, "conv2d_fwd: w/y alignment");
@@ -577,6 +613,8 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   Y3D_CHECK(Cin % groups == 0 && Cout % groups == 0, "conv2d_bwd_data: channels not divisible by groups");
   Y3D_CHECK((Cout / groups) % ce == 0, "conv2d_bwd_data: Cout/groups=%d must be a multiple of %d", Cout / groups, ce);
   Y3D_CHECK(xsw >= Cin, "conv2d_bwd_data: xsw < Cin");
+  Y3D_CHECK(stride >= 1 && dsh % stride == 0 && dsw % stride == 0, "conv2d_bwd_data: stride %d must divide the dy strides", stride);
+  Y3D_CHECK(kh * kw <= 64, "conv2d_bwd_data: at most 64 filter taps");
   if (check_align("conv2d_bwd_data dy", dy, dsb, dsh, dsw, ce)) return Y3D_ERR_INVALID;
   ConvP p;
   p.x = dy; p.w = w_packed_dgrad; p.bias = nullptr; p.y = dx; p.part = nullptr;
@@ -593,11 +631,11 @@ int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_
   int bpk = dtype == Y3D_BF16 ? 64 : 32;
   long M = (long)B * Ho * Wo;
   long tiles = (long)cdiv(kh * kw * Cin_g, 128) * cdiv(Cout / groups, 128) * groups;
-  long want = cdiv(1024, tiles);
+  long want = cdiv(512, tiles);  // ~2 workgroups per CU; every extra split is one more fp32 slab to write and re-read
   long maxs = cdiv(M, bpk);
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
-  if (want > 256) want = 256;
+  if (want > 128) want = 128;
   return (int)want;
 }
 

@@ -469,8 +469,8 @@ int y3d_proj_bwd_data(int dtype, const void* dy, int64_t dsw, const float* w, vo
 }
 
 int y3d_proj_blocks(int64_t P) {
-  long n = (P + 255) / 256;
-  return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+  long n = (P + 511) / 512;
+  return (int)(n < 1 ? 1 : (n > 128 ? 128 : n));
 }
 
 int y3d_proj_bwd_weight(int dtype, const void* x, int64_t xsw, const void* dy, int64_t dsw, float* slab, float* bias_slab,

@@ -58,14 +58,16 @@ def keypoints_3d(center, dep, size3d, hbin, hres, calib):
     ry = ang.unsqueeze(-1) + torch.arctan2(center[..., 0:1] - cu, fu)
     ry = torch.where(ry > math.pi, ry - 2 * math.pi, ry)
     ry = torch.where(ry < -math.pi, ry + 2 * math.pi, ry)
-    a = -ry[..., 0]
+    # R = Rx(pi/2) @ Ry(-ry) applied as out_i = sum_j R[j,i] p_j (keypoint_utils.py:87-110), written out explicitly:
+    # a (B,N,3,3) batched matmul costs a library GEMM launch per call for what is 9 multiply-adds per box
+    a = -ry
     ca, sa = torch.cos(a), torch.sin(a)
-    one, zero = torch.ones_like(ca), torch.zeros_like(ca)
-    cxr, sxr = math.cos(math.pi / 2), math.sin(math.pi / 2)
-    Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, cxr, -sxr], [0.0, sxr, cxr]], dtype=ca.dtype, device=ca.device)
-    Ry = torch.stack((ca, zero, sa, zero, one, zero, -sa, zero, ca), -1).reshape(ca.shape + (3, 3))
-    R = torch.matmul(Rx, Ry)
-    return torch.einsum("bnji,bnkj->bnki", R, corners) + loc.unsqueeze(-2)
+    cx_, sx_ = math.cos(math.pi / 2), math.sin(math.pi / 2)
+    px, py, pz = corners[..., 0], corners[..., 1], corners[..., 2]
+    ox = ca * px + (sx_ * sa) * py - (cx_ * sa) * pz
+    oy = cx_ * py + sx_ * pz
+    oz = sa * px - (sx_ * ca) * py + (cx_ * ca) * pz
+    return torch.stack((ox, oy, oz), -1) + loc.unsqueeze(-2)
 
 
 def _topk_mask(metric, k, valid_gt):

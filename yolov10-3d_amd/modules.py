@@ -320,6 +320,7 @@ class v10Detect3d(nn.Module):
     dynamic = False
     export = False
     shape = None
+    fused = True  # sibling-branch fusion of the training forward (set False for the per-branch reference form)
 
     def __init__(self, nc=80, ch=(), dsconv=False, channels=None, use_predecessors=False, detach_predecessors=True,
                  deform=False, common_head=False, num_scales=3, half_channels=False, fgdm_predictor=False,
@@ -352,6 +353,7 @@ class v10Detect3d(nn.Module):
 
     # ---- dense (training) path: head.py:718-753 -------------------------------------------------------------
     def forward_feat(self, x, heads):
+        """per-branch form (one head set); kept for API parity with the reference, the training forward uses the fused form"""
         ys, embs = [], []
         for i in range(self.nl):
             feats, emb = [], None
@@ -363,6 +365,40 @@ class v10Detect3d(nn.Module):
             ys.append(_proj([module[i][2] for module in heads], feats))
             embs.append(emb)
         return ys, embs
+
+    def _stacks(self, i):
+        """StackedConvs of level i over [o2o branches 0..7, o2m branches 0..7] for layer 1 and (uniform widths only) layer 2"""
+        key = (i, id(self.o2o_heads), id(self.o2m_heads))
+        cache = self.__dict__.setdefault("_stack_cache", {})
+        if key not in cache:
+            branches = [h[i] for h in self.o2o_heads] + [h[i] for h in self.o2m_heads]
+            mids = [b[0].conv.out_channels for b in branches]
+            s1 = ops.StackedConvs([b[0] for b in branches])
+            s2 = ops.StackedConvs([b[1] for b in branches], groups=len(branches)) if len(set(mids)) == 1 else None
+            cache[key] = (branches, mids, s1, s2)
+        return cache[key]
+
+    def forward_train_fused(self, x):
+        """Both head sets of one level as: ONE 3x3 conv Cin -> sum(mid) (the one-to-one half contributes no input gradient:
+        it sees x.detach(), head.py:820), ONE grouped conv (16 groups of mid -> mid), ONE projection launch set writing the
+        (B, 2*no, H, W) map.  Numerically identical to the per-branch form (BatchNorm is per channel)."""
+        o2o, o2m, e_o2o, e_o2m = [], [], [], []
+        for i in range(self.nl):
+            branches, mids, s1, s2 = self._stacks(i)
+            half = sum(mids[:8])
+            z1 = ops.FusedConvBNActFn.apply(x[i], s1, 1, (half, sum(mids)), *s1.params())
+            offs = [sum(mids[:j]) for j in range(16)]
+            if s2 is not None:
+                z2 = ops.FusedConvBNActFn.apply(z1, s2, len(branches), None, *s2.params())
+                out = ops.HeadProjSlicesFn.apply(z2, offs, mids, 16, *[b[2].weight for b in branches], *[b[2].bias for b in branches])
+            else:
+                feats = [b[1](z1[:, o:o + m]) for b, o, m in zip(branches, offs, mids)]
+                out = _proj([b[2] for b in branches], feats)
+            o2o.append(out[:, : self.no])
+            o2m.append(out[:, self.no:])
+            e_o2o.append(z1[:, offs[6]:offs[6] + mids[6]])
+            e_o2m.append(z1[:, offs[14]:offs[14] + mids[14]])
+        return o2o, o2m, e_o2o, e_o2m
 
     # ---- sparse (eval) path: head.py:656-716 -----------------------------------------------------------------
     def select_candidates(self, scores):
@@ -421,8 +457,11 @@ class v10Detect3d(nn.Module):
         if not self.training:
             maps = self.inference_forward_feat([xi.detach() for xi in x], self.o2o_heads)
             return {"one2one": (self.decode(maps), maps), "o2o_embs": None}
-        one2one, o2o_embs = self.forward_feat([xi.detach() for xi in x], self.o2o_heads)
-        one2many, o2m_embs = self.forward_feat(x, self.o2m_heads)
+        if self.fused:
+            one2one, one2many, o2o_embs, o2m_embs = self.forward_train_fused(x)
+        else:
+            one2one, o2o_embs = self.forward_feat([xi.detach() for xi in x], self.o2o_heads)
+            one2many, o2m_embs = self.forward_feat(x, self.o2m_heads)
         return {"one2many": one2many, "one2one": one2one, "o2m_embs": o2m_embs, "o2o_embs": o2o_embs, "depth_maps": torch.empty(1)}
 
     def bias_init(self):

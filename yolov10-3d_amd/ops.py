@@ -117,6 +117,150 @@ TIMER = None  # set by bench.py
 # ------------------------------------------------------------------------------------------------------
 # Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
 # ------------------------------------------------------------------------------------------------------
+def _timed(key, launch):
+    if TIMER is not None:
+        TIMER.bracket(key, launch)
+    else:
+        launch()
+
+
+def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum):
+    """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs."""
+    L = lib()
+    _require_gpu(x)
+    dtype = _COMPUTE_DTYPE
+    dt, c = code(dtype), ce(dtype)
+    st = stream()
+    dev = x.device
+    B, Cin, H, W = x.shape
+    Cout, Cg_w, kh, kw = w32.shape
+    assert kh == k and kw == k and Cin // g == Cg_w, "Conv: weight shape does not match input"
+    Ho = (H + 2 * p - k) // s + 1
+    Wo = (W + 2 * p - k) // s + 1
+    M = B * Ho * Wo
+    dw = g > 1 and g == Cin and g == Cout
+    # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
+    Cin_k = Cin
+    if Cin % c != 0:
+        if g != 1:
+            raise Y3DError(f"grouped conv with {Cin} channels is not 16-byte chunkable")
+        Cin_k = (Cin + c - 1) // c * c
+        xin = nhwc_empty(B, Cin_k, H, W, dtype, dev)
+        L.nchw_to_nhwc(dt, x.float().contiguous().data_ptr(), xin.data_ptr(), B, Cin, H, W, Cin_k, st)
+    else:
+        xin = to_nhwc(x, dtype)
+    sb, sh, sw = s3(xin)
+    y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+    part = None
+    if dw:
+        if Cout % c != 0:
+            raise Y3DError(f"depth-wise conv with {Cout} channels is not 16-byte chunkable")
+        nblk = L.dw_blocks(M)
+        if training:
+            part = _f32(nblk * Cout * 2, dev)
+        wp = _f32(k * k * Cout, dev)
+        L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+        L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
+                       part.data_ptr() if training else None, st)
+    else:
+        nblk = L.conv_stat_blocks(B, Ho, Wo)
+        if training:
+            part = _f32(nblk * Cout * 2, dev)
+        Cg_pad = Cin_k // g
+        wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
+        L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
+        _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
+               lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
+                                    k, k, s, p, part.data_ptr() if training else None, st))
+    stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
+    if training:
+        L.bn_finalize(part.data_ptr(), nblk, Cout, M, g32.data_ptr(), b32.data_ptr(), eps, momentum, rm.data_ptr(), rv.data_ptr(),
+                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
+    else:
+        L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
+    z = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+    rr = None
+    if res_mode:
+        rr = to_nhwc(res, dtype, dense=True)
+        assert rr.shape == z.shape, "residual shape mismatch"
+    L.bn_act_fwd(dt, y.data_ptr(), Cout, stats[2].data_ptr(), stats[3].data_ptr(), int(act), res_mode,
+                 rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), Cout, M, Cout, st)
+    cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act))
+    return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
+
+
+def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
+    """-> dx, dW (fp32 OIHW), dgamma, dbeta, dres.  dx_range=(lo, hi): only output channels lo..hi feed dx
+    (the one-to-one head sees a detached input, reference head.py:820)."""
+    L = lib()
+    xin, w32, y, stats, rr = saved
+    B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg
+    if not training:
+        raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
+    dt = code(dtype)
+    st = stream()
+    dev = dz.device
+    esz = 2 if dtype == torch.bfloat16 else 4
+    M = B * Ho * Wo
+    dz = to_nhwc(dz, dtype, dense=True)
+    nb = L.bn_bwd_blocks(M)
+    part = _f32(nb * Cout * 2, dev)
+    rptr = rr.data_ptr() if rr is not None else None
+    rsw = rr.stride(3) if rr is not None else 0
+    L.bn_act_bwd_reduce(dt, y.data_ptr(), Cout, dz.data_ptr(), dz.stride(3), rptr, rsw, stats[2].data_ptr(), stats[3].data_ptr(),
+                        stats[0].data_ptr(), stats[1].data_ptr(), act, res_mode, part.data_ptr(), M, Cout, st)
+    dgb = _f32(2 * Cout, dev).view(2, Cout)
+    L.bn_bwd_finalize(part.data_ptr(), nb, Cout, M, dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stats[4].data_ptr(), stats[5].data_ptr(), st)
+    dy = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+    dres = None
+    if res_mode == 2 and need_dres:
+        dres = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+    L.bn_act_bwd_apply(dt, y.data_ptr(), Cout, dz.data_ptr(), dz.stride(3), rptr, rsw, stats[2].data_ptr(), stats[3].data_ptr(),
+                       stats[0].data_ptr(), stats[1].data_ptr(), stats[4].data_ptr(), stats[5].data_ptr(), act, res_mode, 1,
+                       dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
+    if res_mode == 1:
+        dres = dz
+    sb, sh, sw = s3(xin)
+    dx = None
+    dW = torch.empty_like(w32)
+    if dw:
+        wp = _f32(k * k * Cout, dev)
+        L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+        if need_dx:
+            dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+            dsb, dsh, dsw = s3(dy)
+            L.dwconv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wp.data_ptr(), dx.data_ptr(), Cin, H, W, k, k, s, p, st)
+        slab = _f32(L.dw_blocks(M) * k * k * Cout, dev)
+        L.dwconv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, dy.data_ptr(), Cout, Ho, Wo, k, k, s, p, slab.data_ptr(),
+                              dW.data_ptr(), 0, st)
+    else:
+        if need_dx and Cin_k == Cin:
+            lo, hi = dx_range if dx_range is not None else (0, Cout)
+            assert g == 1 or (lo, hi) == (0, Cout)
+            co = hi - lo
+            kp = L.conv_kpad(dt, k * k * (co // g))
+            wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
+            L.pack_weight_dgrad(dt, w32.data_ptr() + lo * (Cin // g) * k * k * 4, wpd.data_ptr(), co, Cin // g, g, k, k, st)
+            dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+            dsb, dsh, dsw = s3(dy)
+            _timed(("conv_dgrad", dt, B, H, W, Cin, co, k, s, g),
+                   lambda: L.conv2d_bwd_data(dt, dy.data_ptr() + lo * esz, dsb, dsh, dsw, B, Ho, Wo, co, wpd.data_ptr(), dx.data_ptr(), Cin, H, W,
+                                             Cin, g, k, k, s, p, st))
+        ns = L.conv2d_wgrad_splits(dt, B, Ho, Wo, Cout, Cin_k // g, g, k, k)
+        slab = _f32(ns * Cout * k * k * (Cin_k // g), dev)
+        _timed(("conv_wgrad", dt, B, H, W, Cin_k, Cout, k, s, g),
+               lambda: L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k,
+                                           s, p, slab.data_ptr(), ns, dW.data_ptr(), 0, st))
+    return dx, dW, dgb[0], dgb[1], dres
+
+
+def _w32(weight):
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    return w
+
+
 class ConvBNActFn(torch.autograd.Function):
     """act(bn(conv(x))) (+res)   — reference nn/modules/conv.py:120-122 plus the residual adds of
     block.py:342,711,758,816-817 fused into the BN-apply kernel.
@@ -125,149 +269,92 @@ class ConvBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, res, res_mode, m):
-        L = lib()
-        _require_gpu(x)
-        dtype = _COMPUTE_DTYPE
-        dt, c = code(dtype), ce(dtype)
-        st = stream()
-        dev = x.device
-        B, Cin, H, W = x.shape
-        Cout, Cg_w, kh, kw = weight.shape
-        k, s, p, g = m.k, m.s, m.p, m.g
-        assert kh == k and kw == k and Cin // g == Cg_w, "Conv: weight shape does not match input"
-        Ho = (H + 2 * p - k) // s + 1
-        Wo = (W + 2 * p - k) // s + 1
-        M = B * Ho * Wo
-        dw = g > 1 and g == Cin and g == Cout
-        training = m.training
-        # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
-        Cin_k = Cin
-        if Cin % c != 0:
-            if g != 1:
-                raise Y3DError(f"grouped conv with {Cin} channels is not 16-byte chunkable")
-            Cin_k = (Cin + c - 1) // c * c
-            xin = nhwc_empty(B, Cin_k, H, W, dtype, dev)
-            L.nchw_to_nhwc(dt, x.float().contiguous().data_ptr(), xin.data_ptr(), B, Cin, H, W, Cin_k, st)
-        else:
-            xin = to_nhwc(x, dtype)
-        sb, sh, sw = s3(xin)
-        y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
-        w32 = weight.detach()
-        if w32.dtype != torch.float32 or not w32.is_contiguous():
-            w32 = w32.float().contiguous()
-        part = None
-        if dw:
-            if Cout % c != 0:
-                raise Y3DError(f"depth-wise conv with {Cout} channels is not 16-byte chunkable")
-            nblk = L.dw_blocks(M)
-            if training:
-                part = _f32(nblk * Cout * 2, dev)
-            wp = _f32(k * k * Cout, dev)
-            L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
-            L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
-                           part.data_ptr() if training else None, st)
-        else:
-            nblk = L.conv_stat_blocks(B, Ho, Wo)
-            if training:
-                part = _f32(nblk * Cout * 2, dev)
-            Cg_pad = Cin_k // g
-            wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
-            L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
-            launch = lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo,
-                                          Cout, g, k, k, s, p, part.data_ptr() if training else None, st)
-            if TIMER is not None:
-                TIMER.bracket(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g), launch)
-            else:
-                launch()
-        stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
-        g32 = gamma.detach().float()
-        b32 = beta.detach().float()
-        if training:
-            L.bn_finalize(part.data_ptr(), nblk, Cout, M, g32.data_ptr(), b32.data_ptr(), m.eps, m.momentum,
-                          m.bn.running_mean.data_ptr(), m.bn.running_var.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-                          stats[2].data_ptr(), stats[3].data_ptr(), st)
+        z, cfg, saved = _cba_forward(x, _w32(weight), gamma.detach().float(), beta.detach().float(), m.bn.running_mean, m.bn.running_var,
+                                     m.k, m.s, m.p, m.g, m.has_act, res, res_mode, m.training, m.eps, m.momentum)
+        if m.training:
             m._nbt_pending += 1
-        else:
-            L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), m.bn.running_mean.data_ptr(), m.bn.running_var.data_ptr(), m.eps,
-                            stats[2].data_ptr(), stats[3].data_ptr(), st)
-        z = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
-        rr = None
-        if res_mode:
-            rr = to_nhwc(res, dtype, dense=True)
-            assert rr.shape == z.shape, "residual shape mismatch"
-        L.bn_act_fwd(dt, y.data_ptr(), Cout, stats[2].data_ptr(), stats[3].data_ptr(), int(m.has_act), res_mode,
-                     rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), Cout, M, Cout, st)
-        ctx.m = m
-        ctx.cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype)
-        ctx.save_for_backward(xin, w32, y, stats, rr if res_mode == 2 else None)
+        ctx.cfg = cfg
+        ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        L = lib()
-        xin, w32, y, stats, rr = ctx.saved_tensors
-        B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype = ctx.cfg
-        if not training:
-            raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
-        m = ctx.m
-        dt = code(dtype)
-        st = stream()
-        dev = dz.device
-        M = B * Ho * Wo
-        dz = to_nhwc(dz, dtype, dense=True)
-        nb = L.bn_bwd_blocks(M)
-        part = _f32(nb * Cout * 2, dev)
-        rptr = rr.data_ptr() if rr is not None else None
-        rsw = rr.stride(3) if rr is not None else 0
-        act = int(m.has_act)
-        L.bn_act_bwd_reduce(dt, y.data_ptr(), Cout, dz.data_ptr(), dz.stride(3), rptr, rsw, stats[2].data_ptr(), stats[3].data_ptr(),
-                            stats[0].data_ptr(), stats[1].data_ptr(), act, res_mode, part.data_ptr(), M, Cout, st)
-        dgb = _f32(2 * Cout, dev).view(2, Cout)
-        L.bn_bwd_finalize(part.data_ptr(), nb, Cout, M, dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stats[4].data_ptr(), stats[5].data_ptr(), st)
-        dy = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
-        dres = None
-        if res_mode == 2 and ctx.needs_input_grad[4]:
-            dres = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
-        L.bn_act_bwd_apply(dt, y.data_ptr(), Cout, dz.data_ptr(), dz.stride(3), rptr, rsw, stats[2].data_ptr(), stats[3].data_ptr(),
-                           stats[0].data_ptr(), stats[1].data_ptr(), stats[4].data_ptr(), stats[5].data_ptr(), act, res_mode, 1,
-                           dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
-        if res_mode == 1:
-            dres = dz
-        sb, sh, sw = s3(xin)
-        dx = None
-        dW = torch.empty_like(w32)
-        if dw:
-            wp = _f32(k * k * Cout, dev)
-            L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
-            if ctx.needs_input_grad[0]:
-                dx = nhwc_empty(B, Cin, H, W, dtype, dev)
-                dsb, dsh, dsw = s3(dy)
-                L.dwconv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wp.data_ptr(), dx.data_ptr(), Cin, H, W, k, k, s, p, st)
-            slab = _f32(L.dw_blocks(M) * k * k * Cout, dev)
-            L.dwconv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, dy.data_ptr(), Cout, Ho, Wo, k, k, s, p, slab.data_ptr(),
-                                  dW.data_ptr(), 0, st)
-        else:
-            if ctx.needs_input_grad[0] and Cin_k == Cin:
-                kp = L.conv_kpad(dt, k * k * (Cout // g))
-                wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
-                L.pack_weight_dgrad(dt, w32.data_ptr(), wpd.data_ptr(), Cout, Cin // g, g, k, k, st)
-                dx = nhwc_empty(B, Cin, H, W, dtype, dev)
-                dsb, dsh, dsw = s3(dy)
-                launch = lambda: L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, W,
-                                                   Cin, g, k, k, s, p, st)
-                if TIMER is not None:
-                    TIMER.bracket(("conv_dgrad", dt, B, H, W, Cin, Cout, k, s, g), launch)
-                else:
-                    launch()
-            ns = L.conv2d_wgrad_splits(dt, B, Ho, Wo, Cout, Cin_k // g, g, k, k)
-            slab = _f32(ns * Cout * k * k * (Cin_k // g), dev)
-            launch = lambda: L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k,
-                                                 s, p, slab.data_ptr(), ns, dW.data_ptr(), 0, st)
-            if TIMER is not None:
-                TIMER.bracket(("conv_wgrad", dt, B, H, W, Cin_k, Cout, k, s, g), launch)
-            else:
-                launch()
-        return dx, dW, dgb[0], dgb[1], dres, None, None
+        dx, dW, dg, db, dres = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], ctx.needs_input_grad[4])
+        return dx, dW, dg, db, dres, None, None
+
+
+class StackedConvs:
+    """N sibling Conv modules (same input, kernel, stride) run as ONE convolution with their output channels stacked
+    (the 8 branches x 2 head sets of v10Detect3d share their input).  The per-branch Parameters / BN buffers
+    keep their identity and state_dict keys; their storage is re-pointed at slices of one flat tensor, so stacking costs
+    nothing per step and optimizer / DDP / load_state_dict keep working on the per-branch tensors."""
+
+    def __init__(self, convs, groups=1):
+        self.convs = list(convs)
+        self.groups = groups
+        self.couts = [c.conv.out_channels for c in self.convs]
+        self.flat = {}
+
+    def _ensure(self, name, tensors, setter):
+        flat = self.flat.get(name)
+        ok = flat is not None and flat.device == tensors[0].device
+        if ok:
+            base, off = flat.data_ptr(), 0
+            for t in tensors:
+                if t.data_ptr() != base + off * 4:
+                    ok = False
+                    break
+                off += t.numel()
+        if not ok:
+            flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+            off = 0
+            for i, t in enumerate(tensors):
+                n = t.numel()
+                setter(i, flat[off:off + n].view(t.shape))
+                off += n
+            self.flat[name] = flat
+        return flat
+
+    def tensors(self):
+        cs = self.convs
+        w = self._ensure("w", [c.conv.weight for c in cs], lambda i, v: setattr(cs[i].conv.weight, "data", v))
+        gm = self._ensure("g", [c.bn.weight for c in cs], lambda i, v: setattr(cs[i].bn.weight, "data", v))
+        bt = self._ensure("b", [c.bn.bias for c in cs], lambda i, v: setattr(cs[i].bn.bias, "data", v))
+        rm = self._ensure("rm", [c.bn.running_mean for c in cs], lambda i, v: cs[i].bn._buffers.__setitem__("running_mean", v))
+        rv = self._ensure("rv", [c.bn.running_var for c in cs], lambda i, v: cs[i].bn._buffers.__setitem__("running_var", v))
+        c0 = cs[0].conv
+        return w.view(sum(self.couts), c0.in_channels // c0.groups, *c0.kernel_size), gm, bt, rm, rv
+
+    def params(self):
+        return [c.conv.weight for c in self.convs] + [c.bn.weight for c in self.convs] + [c.bn.bias for c in self.convs]
+
+
+class FusedConvBNActFn(torch.autograd.Function):
+    """One conv+BN+SiLU over the stacked output channels of `stack.convs`.  args: x, stack, groups, dx_range, *params
+    (params only tie the per-branch Parameters into the autograd graph; the math runs on the stacked storage)."""
+
+    @staticmethod
+    def forward(ctx, x, stack, groups, dx_range, *params):
+        w, gm, bt, rm, rv = stack.tensors()
+        m = stack.convs[0]
+        z, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum)
+        if m.training:
+            for c in stack.convs:
+                c._nbt_pending += 1
+        ctx.cfg, ctx.couts, ctx.dx_range = cfg, stack.couts, dx_range
+        ctx.save_for_backward(*saved)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range)
+        dWs, dgs, dbs, off = [], [], [], 0
+        for co in ctx.couts:
+            dWs.append(dW[off:off + co])
+            dgs.append(dg[off:off + co])
+            dbs.append(db[off:off + co])
+            off += co
+        return (dx, None, None, None, *dWs, *dgs, *dbs)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -347,6 +434,73 @@ class HeadProjFn(torch.autograd.Function):
             dbs.append(db)
             off += co
         return (None, *dxs, *dws, *dbs)
+
+
+class HeadProjSlicesFn(torch.autograd.Function):
+    """Same projections as HeadProjFn, but every branch reads a channel slice [off_j, off_j+cin_j) of ONE stacked feature
+    tensor and the backward writes each branch's input gradient straight into its slice of one gradient tensor
+    (no per-branch narrow()/add round trips through autograd).  args: x_full, offsets, cins, n, w_0.., b_0.."""
+
+    @staticmethod
+    def forward(ctx, x, offsets, cins, n, *args):
+        L = lib()
+        ws, bs = args[:n], args[n:2 * n]
+        dtype = _COMPUTE_DTYPE
+        dt = code(dtype)
+        st = stream()
+        x = to_nhwc(x, dtype, dense=True)
+        B, Ct, H, W = x.shape
+        P = B * H * W
+        couts = [w.shape[0] for w in ws]
+        tot = sum(couts)
+        out = nhwc_empty(B, tot, H, W, dtype, x.device)
+        esz = out.element_size()
+        w32 = [w.detach().float().contiguous() for w in ws]
+        b32 = [b.detach().float().contiguous() for b in bs]
+        off = 0
+        for xo, ci, w, b, co in zip(offsets, cins, w32, b32, couts):
+            assert co <= 24
+            L.proj_fwd(dt, x.data_ptr() + xo * esz, x.stride(3), w.data_ptr(), b.data_ptr(), out.data_ptr() + off * esz, tot, P, ci, co, st)
+            off += co
+        ctx.meta = (offsets, cins, n, couts, dtype)
+        ctx.save_for_backward(x, *w32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = lib()
+        offsets, cins, n, couts, dtype = ctx.meta
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dt = code(dtype)
+        st = stream()
+        if not (dout.dtype == dtype and px_dense(dout)):
+            dout = _dense_any(dout, dtype)
+        B, Ct, H, W = x.shape
+        P = B * H * W
+        dev = x.device
+        esz = x.element_size()
+        dsw = dout.stride(3)
+        nb = L.proj_blocks(P)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            covered = sum(cins) == Ct
+            dx = nhwc_empty(B, Ct, H, W, dtype, dev)
+            if not covered:
+                dx.zero_()
+        dws, dbs, off = [], [], 0
+        slab = _f32(nb * max(co * ci for co, ci in zip(couts, cins)), dev)
+        bslab = _f32(nb * max(couts), dev)
+        for xo, ci, w, co in zip(offsets, cins, ws, couts):
+            if dx is not None:
+                L.proj_bwd_data(dt, dout.data_ptr() + off * esz, dsw, w.data_ptr(), dx.data_ptr() + xo * esz, Ct, P, ci, co, st)
+            dW = torch.empty_like(w)
+            db = _f32(co, dev)
+            L.proj_bwd_weight(dt, x.data_ptr() + xo * esz, x.stride(3), dout.data_ptr() + off * esz, dsw, slab.data_ptr(), bslab.data_ptr(),
+                              dW.data_ptr(), db.data_ptr(), 0, P, ci, co, st)
+            dws.append(dW)
+            dbs.append(db)
+            off += co
+        return (dx, None, None, None, *dws, *dbs)
 
 
 def _dense_any(x, dtype):
