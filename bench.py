@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--infer-steps", type=int, default=10)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (rehearsal of the N>1 path on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -142,11 +144,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from yolov10_3d_amd import ddp
+    ddp.init(args.backend, dev)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     y3d.set_compute_dtype(dtype)
@@ -154,16 +157,15 @@ def main():
     model = y3d.YOLOv10_3DDetectionModel(args.model).to(dev).train()
     opt = build_optimizer(model)
     net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
+    model.model[-1].restack()  # sibling-branch parameter stacking must be in place before DDP records parameters / buffers
+    if world > 1 or os.environ.get("Y3D_FORCE_DDP"):
+        net = ddp.wrap(model, device_ids=[local])
     B, S = args.batch, args.imgsz
     batch = synth_batch(B, S, S, seed=1 + rank, device=dev)  # resident in HBM before the timed region
 
     def step():
         loss, items = net(batch)
-        if world > 1:
-            loss = loss * world  # reference trainer.py:401-402 (DDP averages gradients)
-        loss.backward()
+        ddp.scale_loss(loss, world).backward()  # reference trainer.py:401-402 (the all-reduce averages gradients)
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)  # trainer.py:570
         opt.step()
         opt.zero_grad(set_to_none=True)

@@ -308,15 +308,18 @@ struct WgradP {
 template <typename T> struct TFrag;
 template <> struct TFrag<bf16_t> {
   // LDS tile [pixel][128 elements] (256-byte rows); one MFMA k-sub-step = 32 pixels.
-  // A/B fragment: element j of lane l = tile[k0 + 8*(l>>4) + j][i0 + (l&15)] via two transposed 4x16 block reads.
+  // A/B fragment: two transposed 4x16 block reads.  The pixel <-> MFMA-k assignment is a free permutation of the reduction
+  // index (A and B use the same one): k = 8g+j  <->  pixel row k0 + 16*(j>>2) + 4g + (j&3), so that the two 16-lane groups of a
+  // 32-lane half read 8 CONSECUTIVE rows per instruction, which the padded pitch spreads over all 64 banks.
   typedef bf16x8_t type;
   static constexpr int KSUB_PX = 32;
+  static constexpr int PITCH = 256 + 32;  // +32 B per pixel row: the 8 rows a 32-lane half touches in one transposed read cover all 64 banks once
   __device__ static __forceinline__ type load(const char* tile, int i0, int k0, int lane) {
     int grp = lane >> 4, li = lane & 15;
     int q = li >> 2, pp = li & 3;
-    const char* a0 = tile + (k0 + 8 * grp + q) * 256 + (i0 + 4 * pp) * 2;
+    const char* a0 = tile + (k0 + 4 * grp + q) * PITCH + (i0 + 4 * pp) * 2;
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
-    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * 256));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 16 * PITCH));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, v);
@@ -329,8 +332,9 @@ template <> struct TFrag<float> {
   // LDS tile [pixel][128 floats] (512-byte rows); one MFMA k-sub-step = 4 pixels.
   typedef float type;
   static constexpr int KSUB_PX = 4;
+  static constexpr int PITCH = 512 + 64;  // row r+1 lands 16 banks after row r: the 2 rows x 16 floats of a half are conflict-free
   __device__ static __forceinline__ type load(const char* tile, int i0, int k0, int lane) {
-    return *(const float*)(tile + (k0 + (lane >> 4)) * 512 + (i0 + (lane & 15)) * 4);
+    return *(const float*)(tile + (k0 + (lane >> 4)) * PITCH + (i0 + (lane & 15)) * 4);
   }
   __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -342,8 +346,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int CE = TT<T>::CE;
   constexpr int BPK = TT<T>::BKE;            // 64 pixels (bf16) / 32 pixels (fp32) per step: 16 KB per operand tile
-  constexpr int ROWB = 128 * sizeof(T);      // bytes per pixel row
-  constexpr int CPR = ROWB / 16;             // chunks per row (16 / 32)
+  constexpr int ROWD = 128 * sizeof(T);      // data bytes per pixel row
+  constexpr int ROWB = TFrag<T>::PITCH;      // LDS row pitch (padded against bank conflicts)
+  constexpr int CPR = ROWD / 16;             // chunks per row (16 / 32)
   constexpr int NCH = BPK * CPR / 256;       // chunks per thread per operand (4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sD = smem;                 // [2][BPK][ROWB]  dy tile  (pixel x co)
@@ -661,7 +666,7 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
   p.chunk_px = cdiv(cdiv(p.M, nsplit), bpk) * bpk;
   dim3 grid(cdiv(p.Ktot, 128), cdiv(p.Cn, 128), groups * nsplit);
   hipStream_t st = (hipStream_t)stream;
-  size_t sm = 4 * 16384;
+  size_t sm = dtype == Y3D_BF16 ? 4 * 64 * (256 + 32) : 4 * 32 * (512 + 64);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), sm, st, p);
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), sm, st, p);
   Y3D_LAUNCH_CHECK();

@@ -378,6 +378,15 @@ class v10Detect3d(nn.Module):
             cache[key] = (branches, mids, s1, s2)
         return cache[key]
 
+    def restack(self):
+        """(re)establish the stacked parameter storage of the fused training forward now (e.g. before wrapping the model in
+        DistributedDataParallel, after .to(device) / load_state_dict(assign=True) / deepcopy)"""
+        for i in range(self.nl):
+            _, _, s1, s2 = self._stacks(i)
+            s1.tensors()
+            if s2 is not None:
+                s2.tensors()
+
     def forward_train_fused(self, x):
         """Both head sets of one level as: ONE 3x3 conv Cin -> sum(mid) (the one-to-one half contributes no input gradient:
         it sees x.detach(), head.py:820), ONE grouped conv (16 groups of mid -> mid), ONE projection launch set writing the
