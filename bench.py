@@ -232,7 +232,7 @@ def main():
             flops = 2.0 * B * P3 * P3 * 16 * mid * mid * 9
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
-            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s,128,128,2,2,fwd> 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
+            roof = {"bound": "mfma", "kernel": "conv3x3_tile_kernel<%s,TH=16> (resident-halo implicit GEMM) 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None

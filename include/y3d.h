@@ -46,8 +46,11 @@ int y3d_pack_weight_fwd(int dtype, const float* w_oihw, void* out, int Cout, int
 /* OIHW fp32 parameter -> [G][Cin_g][kh*kw][Cout_g] (row pitch y3d_conv_kpad(dtype, kh*kw*Cout_g)) for the data gradient */
 int y3d_pack_weight_dgrad(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int groups, int kh, int kw, void* stream);
 int y3d_conv_kpad(int dtype, int k_total);
-/* number of BatchNorm partial rows the forward emits: ceil(B*Ho*Wo / 128) */
+/* number of BatchNorm partial rows of the generic implicit-GEMM kernel: ceil(B*Ho*Wo / 128) */
 int y3d_conv_stat_blocks(int B, int Ho, int Wo);
+/* number of BatchNorm partial rows y3d_conv2d_fwd emits for this geometry (depends on the kernel it dispatches to:
+ * 3x3 s1 p1 convs with 128-byte channel slabs run the resident-halo tile kernel, one row per TH x 16 pixel tile) */
+int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
 /* y = conv(x, w) (+bias).  stat_partials (optional, no bias): [y3d_conv_stat_blocks][Cout][2] = per-block (sum, sum^2) of y. */
 int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
                    const void* w_packed, const float* bias, void* y, int64_t ysw, int Ho, int Wo, int Cout, int groups,
@@ -149,6 +152,28 @@ int y3d_attn_fwd(int dtype, const void* qkv, int64_t qsw, void* out, int64_t osw
 int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64_t osw, const void* dout, int64_t dsw,
                  const void* dv_extra, int64_t esw, const float* lse, float* delta, void* dqkv, int64_t gsw, int B, int N, int nh,
                  int kd, int hd, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3D task-aligned assignment + 3D detection loss (tal_loss3d.hip)
+ * replaces TaskAlignedAssigner3d.forward utils/tal.py:392-452 (+ keypoint_utils.py:11-118, metrics.py:78-134) and
+ * DDDetectionLoss.__call__ utils/loss.py:821-963 for one head set.
+ * maps[l]: (B, H[l], W[l], >= nc+35) NHWC head map of level l (pointer at channel 0 of the head set, pixel stride psw[l]);
+ * anchors are level-major, row-major (tal.py:300-312).  gt: (B, n, 17) padded targets of loss.py:795-810
+ * (cls | box xyxy px | center_2d | size_2d | center_3d | size_3d | depth | heading_bin | heading_res).
+ * ---------------------------------------------------------------------------------------------- */
+int y3d_tal3d_scratch_floats(int B, int n, int A, int topk);
+/* outputs: fg_mask (B,A) uint8, target_gt_idx (B,A) int32, target_scores (B,A,nc) fp32 (normalised),
+ * scal[0] = max(sum(target_scores), 1), scal[1] = number of foreground anchors */
+int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
+                     int B, int nc, const float* gt, int n, const float* calib, const float* mean_sizes, int topk, float alpha,
+                     float beta, float gamma, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
+                     void* stream);
+/* items[6] = (box2d, cls, depth, offset3d, size3d, heading) of loss.py:886-891; grads[l] (pixel stride gsw[l]) receives
+ * grad_scale * d(sum(items))/d(map) for all nc+35 channels.  partials: 6 * ceil(B*A/256) floats */
+int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, void* const* grads, const int64_t* gsw, const int* H,
+               const int* W, const float* strides, int B, int nc, const float* gt, int n, const uint8_t* fg_mask,
+               const int* target_gt_idx, const float* target_scores, const float* scal, float w_loss2d, float w_cls, float w_depth,
+               float w_offset3d, float w_size3d, float w_heading, float grad_scale, float* partials, float* items, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 // pixel (one 8/16-byte store).  The epilogue optionally emits per-block BatchNorm partial sums
 // (sum, sum of squares per channel), which makes the BN statistics bitwise reproducible (no atomics).
 #include "common.h"
+#include "conv_frag.h"
 
 namespace {
 
@@ -31,34 +32,6 @@ struct ConvP {
   int Ktot, Kpad;  // taps*Cg and its padding to a chunk multiple (row pitch of packed weights)
   int M;           // B*Hq*Wq
   int ntx, nty;    // tile grid (pixel tiles x channel tiles); the launch is 1-D over ntx*nty, remapped per XCD
-};
-
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> {
-  // one K sub-step = 32 elements = 4 chunks; lane reads chunk (ks*4 + lane>>4) of row (lane&15)
-  static constexpr int KSUB = 2;
-  typedef bf16x8_t type;
-  __device__ static __forceinline__ type load(const char* tile, int row, int ks, int lane) {
-    int r = row + (lane & 15);
-    int c = ks * 4 + (lane >> 4);
-    const uint4* p = (const uint4*)(tile + r * 128 + ((c ^ (r & 7)) << 4));
-    return __builtin_bit_cast(bf16x8_t, *p);
-  }
-  __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Frag<float> {
-  // one K sub-step = 4 elements = 1 chunk; lane reads element (lane>>4) of chunk ks of row (lane&15)
-  static constexpr int KSUB = 8;
-  typedef float type;
-  __device__ static __forceinline__ type load(const char* tile, int row, int ks, int lane) {
-    int r = row + (lane & 15);
-    return *(const float*)(tile + r * 128 + ((ks ^ (r & 7)) << 4) + ((lane >> 4) << 2));
-  }
-  __device__ static __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
 };
 
 // BP x BC output tile (pixels x channels), 256 threads = WP x WC waves.
@@ -541,9 +514,21 @@ int launch_conv(ConvP p, hipStream_t st) {
 
 }  // namespace
 
+// conv3x3_tile.hip
+int y3d_tile_height(int dtype, int H, int W, int Cg, int kh, int kw, int stride, int pad);
+int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G,
+                            const void* w, int Ktot, void* y, long ysw, float* part, int flip, void* stream);
+
 extern "C" {
 
 int y3d_conv_stat_blocks(int B, int Ho, int Wo) { return cdiv((long)B * Ho * Wo, 128); }
+
+int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
+  int th = groups > 0 ? y3d_tile_height(dtype, H, W, Cin / groups, kh, kw, stride, pad) : 0;
+  if (th) return B * (H / th) * cdiv(W, 16);
+  int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  return cdiv((long)B * Ho * Wo, 128);
+}
 
 int y3d_conv_kpad(int dtype, int k_total) {
   int ce = dtype == Y3D_BF16 ? 8 : 4;
@@ -606,6 +591,10 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
   p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
+  if (!bias) {
+    int th = y3d_tile_height(dtype, H, W, p.Cg, kh, kw, stride, pad);
+    if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, stream);
+  }
   if (dtype == Y3D_BF16) return launch_conv<bf16_t, false>(p, (hipStream_t)stream);
   return launch_conv<float, false>(p, (hipStream_t)stream);
 }
@@ -628,6 +617,12 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   p.Cg = Cout / groups; p.Cn = Cin / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = y3d_conv_kpad(dtype, p.Ktot); p.M = B * H * W;
+  {
+    // a 3x3 s1 p1 data gradient is the same conv on dy with flipped taps (Ho == H, Wo == W)
+    int th = y3d_tile_height(dtype, Ho, Wo, p.Cg, kh, kw, stride, pad);
+    if (th && Ho == H && Wo == W)
+      return y3d_conv3x3_tile_launch(dtype, th, dy, dsb, dsh, dsw, B, H, W, p.Cg, p.Cn, groups, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, stream);
+  }
   if (dtype == Y3D_BF16) return launch_conv<bf16_t, true>(p, (hipStream_t)stream);
   return launch_conv<float, true>(p, (hipStream_t)stream);
 }

@@ -1,0 +1,502 @@
+// Task-aligned assignment (3D) and the 3D detection loss with its gradient, fused for the NHWC head maps.
+//
+// Reference: utils/tal.py:355-753 TaskAlignedAssigner3d (use_2d + use_3d, 'l1' keypoint metric, constrain_anchors),
+// utils/keypoint_utils.py:11-118, utils/metrics.py:78-134 (CIoU), utils/loss.py:821-963, 1112-1136 DDDetectionLoss.
+// The reference materialises (B, n, A, 8, 3) keypoint differences and ~60 small torch ops; here one thread owns one anchor:
+// it decodes its 38 logits straight from the per-level maps, builds its 8 box corners in registers and walks the (<= 64) GT
+// records of its image held in LDS.  All arithmetic is fp32 in the reference's operation order (no FMA contraction), so the
+// integer outputs (fg_mask, target_gt_idx) reproduce the reference's on identical inputs; ties go to the lowest index.
+//
+// Stages (all tiny next to the convolutions, HBM/latency-bound):
+//   gt_prep   (B*n threads)       GT record: label, box, 8 keypoints
+//   metric    (B x A threads)     align[b][g][a], sim[b][g][a]
+//   topk      (one block per (b,g)) k passes of a block-wide arg-max (value desc, index asc) -> candidate anchors
+//   resolve   (B x A threads)     anchor -> fg flag, gt index (multi-assigned: arg-max of sim over ALL gts), atomicMax of the
+//                                 per-GT normalisers (order independent)
+//   scores    (B x A threads)     normalised target scores + block partials of sum(target_scores), n_fg
+//   loss      (B x A threads)     six loss partial sums and d(loss)/d(map) for all 38 channels
+#include "common.h"
+
+namespace {
+
+constexpr int MAXL = 4;
+constexpr int GTW = 40;   // floats per GT record: valid, label, box(4), c2(2), s2(2), c3(2), s3(3), depth, hbin, hres, kps(24) = 42 -> see layout
+// record layout
+constexpr int G_VALID = 0, G_LABEL = 1, G_BOX = 2, G_KPS = 6;  // 6..29 keypoints; raw 17-vector is read from the padded gt tensor
+
+struct Levels {
+  const void* map[MAXL];   // (B, H, W, >=no) NHWC maps, channel 0 of this head set at the pointer
+  void* grad[MAXL];        // same geometry, pixel stride gsw
+  long psw[MAXL];          // pixel stride of map (elements)
+  long gsw[MAXL];
+  int H[MAXL], W[MAXL], a0[MAXL];  // a0: first anchor index of the level
+  float stride[MAXL];
+  int nl, A, B, nc, no;
+};
+
+template <typename T>
+__device__ __forceinline__ const T* anchor_ptr(const Levels& L, int b, int a, float& ax, float& ay, float& st, int& lvl) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MAXL; ++i) if (i < L.nl && a >= L.a0[i]) l = i;
+  int r = a - L.a0[l];
+  int hy = r / L.W[l], hx = r - hy * L.W[l];
+  ax = hx + 0.5f;
+  ay = hy + 0.5f;
+  st = L.stride[l];
+  lvl = l;
+  return (const T*)L.map[l] + (((long)b * L.H[l] + hy) * L.W[l] + hx) * L.psw[l];
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// utils/keypoint_utils.py:11-118 (explicit form of Rx(pi/2) @ Ry(-ry))
+__device__ __forceinline__ void keypoints(float cx, float cy, float dep, float sh, float sw, float sl, int bin, float res,
+                                          const float* cal, float* k) {
+  const float PI = 3.14159265358979323846f;
+  float cu = cal[0], cv = cal[1], fu = cal[2], fv = cal[3], tx = cal[4], ty = cal[5];
+  float X = (cx - cu) * dep / fu + tx;
+  float Y = (cy - cv) * dep / fv + ty;
+  float hl = sl / 2.f, hw = sw / 2.f, hh = sh / 2.f;
+  float ang = (float)bin * (float)(2.0 * 3.14159265358979323846 / 12.0) + res;
+  if (ang > PI) ang = ang - (float)(2.0 * 3.14159265358979323846);
+  float ry = ang + atan2f(cx - cu, fu);
+  if (ry > PI) ry = ry - (float)(2.0 * 3.14159265358979323846);
+  if (ry < -PI) ry = ry + (float)(2.0 * 3.14159265358979323846);
+  float a = -ry;
+  float ca = cosf(a), sa = sinf(a);
+  const float cxr = 6.123233995736766e-17f, sxr = 1.0f;  // cos(pi/2), sin(pi/2) as the reference's Python floats
+  const float sgx[8] = {1, 1, -1, -1, 1, 1, -1, -1};
+  const float sgy[8] = {1, -1, 1, -1, 1, -1, 1, -1};
+  const float sgz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float px = sgx[i] * hl, py = sgy[i] * hw, pz = sgz[i] * hh;
+    float ox = ca * px + (sxr * sa) * py - (cxr * sa) * pz;
+    float oy = cxr * py + sxr * pz;
+    float oz = sa * px - (sxr * ca) * py + (cxr * ca) * pz;
+    k[i * 3 + 0] = ox + X;
+    k[i * 3 + 1] = oy + Y;
+    k[i * 3 + 2] = oz + dep;
+  }
+}
+
+// utils/metrics.py:78-134 bbox_iou(xywh=False, CIoU=True), box1 = gt, box2 = prediction
+__device__ __forceinline__ float ciou_f(const float* g, float x21, float y21, float x22, float y22) {
+  const float eps = 1e-7f;
+  float x11 = g[0], y11 = g[1], x12 = g[2], y12 = g[3];
+  float w1 = x12 - x11, h1 = y12 - y11 + eps;
+  float w2 = x22 - x21, h2 = y22 - y21 + eps;
+  float iw = fminf(x12, x22) - fmaxf(x11, x21);
+  float ih = fminf(y12, y22) - fmaxf(y11, y21);
+  float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+  float uni = w1 * h1 + w2 * h2 - inter + eps;
+  float iou = inter / uni;
+  float cw = fmaxf(x12, x22) - fminf(x11, x21);
+  float ch = fmaxf(y12, y22) - fminf(y11, y21);
+  float c2 = cw * cw + ch * ch + eps;
+  float dx = x21 + x22 - x11 - x12, dy = y21 + y22 - y11 - y12;
+  float rho2 = (dx * dx + dy * dy) / 4.f;
+  float da = atanf(w2 / h2) - atanf(w1 / h1);
+  float v = (float)(4.0 / (3.14159265358979323846 * 3.14159265358979323846)) * (da * da);
+  float alpha = v / (v - iou + (1.f + eps));
+  return iou - (rho2 / c2 + v * alpha);
+}
+
+// gt: (B, n, 17) = cls | box xyxy px | c2(2) | s2(2) | c3(2) | s3(3) | depth | hbin | hres ; rec: (B, n, GTW)
+__global__ void gt_prep_kernel(const float* __restrict__ gt, const float* __restrict__ calib, const float* __restrict__ mean_sizes,
+                               float* __restrict__ rec, int B, int n, int nc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  int b = i / n;
+  const float* g = gt + (long)i * 17;
+  float* r = rec + (long)i * GTW;
+  float bs = g[1] + g[2] + g[3] + g[4];
+  r[G_VALID] = bs > 0.f ? 1.f : 0.f;
+  int lab = (int)g[0];
+  lab = lab < 0 ? 0 : (lab >= nc ? nc - 1 : lab);
+  r[G_LABEL] = (float)lab;
+  for (int j = 0; j < 4; ++j) r[G_BOX + j] = g[1 + j];
+  float sh = mean_sizes[lab * 3 + 0] + g[11], sw = mean_sizes[lab * 3 + 1] + g[12], sl = mean_sizes[lab * 3 + 2] + g[13];
+  keypoints(g[9], g[10], g[14], sh, sw, sl, (int)g[15], g[16], calib + b * 6, r + G_KPS);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __restrict__ rec, const float* __restrict__ calib,
+                                                     const float* __restrict__ mean_sizes, float* __restrict__ align,
+                                                     float* __restrict__ sim, int n, float alpha, float beta, float gamma) {
+  extern __shared__ float sg[];  // [n][GTW]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < n * GTW; i += blockDim.x) sg[i] = rec[(long)b * n * GTW + i];
+  __syncthreads();
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= L.A) return;
+  float ax, ay, st;
+  int lvl;
+  const T* p = anchor_ptr<T>(L, b, a, ax, ay, st, lvl);
+  const int nc = L.nc;
+  float sc[8];
+  int amax = 0;
+  float best = -1.f;
+  for (int c = 0; c < nc && c < 8; ++c) {
+    sc[c] = sigmoid_f(TT<T>::ld(p + c));
+    if (sc[c] > best) { best = sc[c]; amax = c; }
+  }
+  float o2x = TT<T>::ld(p + nc + 0), o2y = TT<T>::ld(p + nc + 1), s2x = TT<T>::ld(p + nc + 2), s2y = TT<T>::ld(p + nc + 3);
+  float ccx = ax + o2x, ccy = ay + o2y;
+  float bx1 = (ccx - s2x / 2.f) * st, by1 = (ccy - s2y / 2.f) * st, bx2 = (ccx + s2x / 2.f) * st, by2 = (ccy + s2y / 2.f) * st;
+  float apx = ax * st, apy = ay * st;
+  float c3x = apx + TT<T>::ld(p + nc + 4) * st, c3y = apy + TT<T>::ld(p + nc + 5) * st;
+  float sh = mean_sizes[amax * 3 + 0] + TT<T>::ld(p + nc + 6), sw = mean_sizes[amax * 3 + 1] + TT<T>::ld(p + nc + 7),
+        sl = mean_sizes[amax * 3 + 2] + TT<T>::ld(p + nc + 8);
+  int hb = 0;
+  float hbv = TT<T>::ld(p + nc + 9);
+  for (int j = 1; j < 12; ++j) {
+    float v = TT<T>::ld(p + nc + 9 + j);
+    if (v > hbv) { hbv = v; hb = j; }
+  }
+  float hres = TT<T>::ld(p + nc + 21 + hb);
+  float dep = TT<T>::ld(p + nc + 33);
+  float kp[24];
+  keypoints(c3x, c3y, dep, sh, sw, sl, hb, hres, calib + b * 6, kp);
+  for (int g = 0; g < n; ++g) {
+    const float* r = sg + g * GTW;
+    float al = 0.f, sm = 0.f;
+    if (r[G_VALID] != 0.f) {
+      // tal.py:709-726: anchor centre strictly inside the box (eps 1e-9)
+      float d0 = apx - r[G_BOX], d1 = apy - r[G_BOX + 1], d2 = r[G_BOX + 2] - apx, d3 = r[G_BOX + 3] - apy;
+      if (fminf(fminf(d0, d1), fminf(d2, d3)) > 1e-9f) {
+        float s = sc[(int)r[G_LABEL]];
+        float ov = fmaxf(ciou_f(r + G_BOX, bx1, by1, bx2, by2), 0.f);
+        float dist = 0.f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) dist += fabsf(kp[j] - r[G_KPS + j]);
+        dist = dist / 24.f;
+        sm = 1.f / expf(dist);
+        float sa = alpha == 0.5f ? sqrtf(s) : (alpha == 1.f ? s : powf(s, alpha));
+        float ob = beta == 1.f ? ov : powf(ov, beta);
+        float sgm = gamma == 1.f ? sm : powf(sm, gamma);
+        al = sa * ob * sgm;
+      }
+    }
+    align[((long)b * n + g) * L.A + a] = al;
+    sim[((long)b * n + g) * L.A + a] = sm;
+  }
+}
+
+// one block per (b, g): k passes of arg-max with (value desc, index asc) order; cand[b][g][j] = anchor index or -1
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ align, const float* __restrict__ rec, int* __restrict__ cand,
+                                                   Levels L, int n, int k) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  __shared__ int chosen[16];
+  const int bg = blockIdx.x, b = bg / n;
+  const float* r = rec + (long)bg * GTW;
+  int* out = cand + (long)bg * k;
+  if (r[G_VALID] == 0.f) {
+    if (threadIdx.x < k) out[threadIdx.x] = -1;
+    return;
+  }
+  const float* row = align + (long)bg * L.A;
+  for (int j = 0; j < k; ++j) {
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int a = threadIdx.x; a < L.A; a += 256) {
+      bool skip = false;
+      for (int t = 0; t < j; ++t) skip |= (chosen[t] == a);
+      if (skip) continue;
+      float v = row[a];
+      if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        float v2 = sv[threadIdx.x + s];
+        int i2 = si[threadIdx.x + s];
+        if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) chosen[j] = si[0];
+    __syncthreads();
+  }
+  if (threadIdx.x < k) {
+    int a = chosen[threadIdx.x];
+    // mask_pos = mask_topk * mask_in_gts * mask_gt (tal.py:492-497): a candidate outside the box is dropped
+    float ax, ay, st;
+    int lvl;
+    (void)b;
+    int l = 0;
+    for (int i = 1; i < MAXL; ++i) if (i < L.nl && a >= L.a0[i]) l = i;
+    int rr = a - L.a0[l];
+    int hy = rr / L.W[l], hx = rr - hy * L.W[l];
+    ax = (hx + 0.5f) * L.stride[l];
+    ay = (hy + 0.5f) * L.stride[l];
+    (void)st; (void)lvl;
+    float d0 = ax - r[G_BOX], d1 = ay - r[G_BOX + 1], d2 = r[G_BOX + 2] - ax, d3 = r[G_BOX + 3] - ay;
+    out[threadIdx.x] = fminf(fminf(d0, d1), fminf(d2, d3)) > 1e-9f ? a : -1;
+  }
+}
+
+// per anchor: how many GTs selected it; the winner; per-GT normalisers by atomicMax on the (non-negative) float bits
+__global__ void resolve_kernel(const int* __restrict__ cand, const float* __restrict__ align, const float* __restrict__ sim,
+                               unsigned char* __restrict__ fg, int* __restrict__ gt_idx, unsigned* __restrict__ pa, unsigned* __restrict__ po,
+                               int B, int n, int A, int k) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * A) return;
+  int b = (int)(i / A), a = (int)(i - (long)b * A);
+  int cnt = 0, gsel = 0;
+  for (int g = 0; g < n; ++g) {
+    const int* c = cand + ((long)b * n + g) * k;
+    bool hit = false;
+    for (int j = 0; j < k; ++j) hit |= (c[j] == a);
+    if (hit) { if (cnt == 0) gsel = g; ++cnt; }
+  }
+  if (cnt > 1) {  // tal.py:741-748: arg-max of `overlaps` (= similarities) over ALL gts, first maximum
+    float bv = -1.f;
+    for (int g = 0; g < n; ++g) {
+      float v = sim[((long)b * n + g) * A + a];
+      if (v > bv) { bv = v; gsel = g; }
+    }
+  }
+  fg[i] = cnt > 0;
+  gt_idx[i] = cnt > 0 ? gsel : 0;
+  if (cnt > 0) {
+    float al = align[((long)b * n + gsel) * A + a], sm = sim[((long)b * n + gsel) * A + a];
+    atomicMax(pa + b * n + gsel, __float_as_uint(al));
+    atomicMax(po + b * n + gsel, __float_as_uint(sm));
+  }
+}
+
+// target_scores (B, A, nc) and block partials (sum of scores, n_fg)
+__global__ __launch_bounds__(256) void scores_kernel(const unsigned char* __restrict__ fg, const int* __restrict__ gt_idx,
+                                                     const float* __restrict__ align, const float* __restrict__ rec,
+                                                     const unsigned* __restrict__ pa, const unsigned* __restrict__ po,
+                                                     float* __restrict__ tscores, float* __restrict__ part, int B, int n, int A, int nc,
+                                                     float eps) {
+  __shared__ float s0[256], s1[256];
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float ts = 0.f, nf = 0.f;
+  if (i < (long)B * A) {
+    int b = (int)(i / A), a = (int)(i - (long)b * A);
+    int lab = -1;
+    float norm = 0.f;
+    if (fg[i]) {
+      int g = gt_idx[i];
+      lab = (int)rec[((long)b * n + g) * GTW + G_LABEL];
+      float al = align[((long)b * n + g) * A + a];
+      norm = al * __uint_as_float(po[b * n + g]) / (__uint_as_float(pa[b * n + g]) + eps);
+      ts = norm;
+      nf = 1.f;
+    }
+    for (int c = 0; c < nc; ++c) tscores[i * nc + c] = c == lab ? norm : 0.f;
+  }
+  s0[threadIdx.x] = ts;
+  s1[threadIdx.x] = nf;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { s0[threadIdx.x] += s0[threadIdx.x + s]; s1[threadIdx.x] += s1[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = s0[0]; part[blockIdx.x * 2 + 1] = s1[0]; }
+}
+
+// scal[0] = max(sum target_scores, 1), scal[1] = n_fg
+__global__ void scal_kernel(const float* __restrict__ part, int nblk, float* __restrict__ scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < nblk; ++i) { a += part[i * 2]; b += part[i * 2 + 1]; }
+    scal[0] = (float)(a > 1.0 ? a : 1.0);
+    scal[1] = (float)b;
+  }
+}
+
+struct LossW { float loss2d, cls, depth, offset3d, size3d, heading; };
+
+// per anchor: six loss terms (already divided by the normalisers) and the gradient of their sum times `gscale` wrt the 38 logits
+template <typename T>
+__global__ __launch_bounds__(256) void loss_kernel(Levels L, const unsigned char* __restrict__ fg, const int* __restrict__ gt_idx,
+                                                   const float* __restrict__ tscores, const float* __restrict__ gt,
+                                                   const float* __restrict__ scal, LossW w, float gscale, float* __restrict__ part,
+                                                   int n) {
+  __shared__ float sh[6][256];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float l[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < (long)L.B * L.A) {
+    const int b = (int)(i / L.A), a = (int)(i - (long)b * L.A);
+    float ax, ay, st;
+    int lvl;
+    const T* p = anchor_ptr<T>(L, b, a, ax, ay, st, lvl);
+    int r = a - L.a0[lvl];
+    int hy = r / L.W[lvl], hx = r - hy * L.W[lvl];
+    T* gp = (T*)L.grad[lvl] + (((long)b * L.H[lvl] + hy) * L.W[lvl] + hx) * L.gsw[lvl];
+    const int nc = L.nc;
+    const float tss = scal[0], nfg = scal[1];
+    float gr[40];
+#pragma unroll
+    for (int c = 0; c < 40; ++c) gr[c] = 0.f;
+    // classification: BCE with logits against the normalised target scores, dense (loss.py:888)
+    for (int c = 0; c < nc; ++c) {
+      float x = TT<T>::ld(p + c), t = tscores[i * nc + c];
+      float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+      l[1] += bce;
+      gr[c] = (sigmoid_f(x) - t) / tss * w.cls;
+    }
+    l[1] = l[1] / tss * w.cls;
+    if (fg[i]) {
+      const float* g = gt + ((long)b * n + gt_idx[i]) * 17;
+      const float apx = ax * st, apy = ay * st;
+      const float inv2 = 1.f / (nfg * 2.f);
+      // 2D box: mean L1 of offset and of size over the fg elements, / tss (loss.py:913-926)
+      float acc2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float po = TT<T>::ld(p + nc + j) * st, to = g[5 + j] - (j == 0 ? apx : apy);
+        float ps = TT<T>::ld(p + nc + 2 + j) * st, tsz = g[7 + j];
+        acc2 += fabsf(po - to) + fabsf(ps - tsz);
+        gr[nc + j] = (po > to ? 1.f : (po < to ? -1.f : 0.f)) * st * inv2 / tss * w.loss2d;
+        gr[nc + 2 + j] = (ps > tsz ? 1.f : (ps < tsz ? -1.f : 0.f)) * st * inv2 / tss * w.loss2d;
+      }
+      l[0] = acc2 * inv2 / tss * w.loss2d;
+      // depth with Laplacian aleatoric uncertainty (loss.py:1112-1119)
+      float d = TT<T>::ld(p + nc + 33), u = TT<T>::ld(p + nc + 34), td = g[14];
+      float e = 1.4142f * expf(-0.5f * u), ad = fabsf(d - td);
+      l[2] = (e * ad + 0.5f * u) / tss * w.depth;
+      gr[nc + 33] = e * (d > td ? 1.f : (d < td ? -1.f : 0.f)) / tss * w.depth;
+      gr[nc + 34] = (-0.5f * e * ad + 0.5f) / tss * w.depth;
+      // 3D offset: mean L1 over fg elements (loss.py:936-940)
+      float acc3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float po = TT<T>::ld(p + nc + 4 + j) * st, to = g[9 + j] - (j == 0 ? apx : apy);
+        acc3 += fabsf(po - to);
+        gr[nc + 4 + j] = (po > to ? 1.f : (po < to ? -1.f : 0.f)) * st * inv2 / tss * w.offset3d;
+      }
+      l[3] = acc3 * inv2 / tss * w.offset3d;
+      // 3D size: summed L1 (loss.py:942-946)
+      float acc4 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float ps = TT<T>::ld(p + nc + 6 + j), tsz = g[11 + j];
+        acc4 += fabsf(ps - tsz);
+        gr[nc + 6 + j] = (ps > tsz ? 1.f : (ps < tsz ? -1.f : 0.f)) / tss * w.size3d;
+      }
+      l[4] = acc4 / tss * w.size3d;
+      // heading: cross entropy over 12 bins + L1 on the residual of the target bin (loss.py:1122-1136)
+      int tb = (int)g[15];
+      float hv[12], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) { hv[j] = TT<T>::ld(p + nc + 9 + j); mx = fmaxf(mx, hv[j]); }
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) se += expf(hv[j] - mx);
+      float lse = mx + logf(se);
+      float pr = TT<T>::ld(p + nc + 21 + tb), tr = g[16];
+      l[5] = (lse - hv[tb] + fabsf(pr - tr)) / tss * w.heading;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) gr[nc + 9 + j] = (expf(hv[j] - lse) - (j == tb ? 1.f : 0.f)) / tss * w.heading;
+      gr[nc + 21 + tb] = (pr > tr ? 1.f : (pr < tr ? -1.f : 0.f)) / tss * w.heading;
+    }
+    for (int c = 0; c < L.no; ++c) TT<T>::st(gp + c, gr[c] * gscale);
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) sh[j][threadIdx.x] = l[j];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[(long)blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ items) {
+  int j = threadIdx.x;
+  if (j < 6) {
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) a += part[(long)i * 6 + j];
+    items[j] = (float)a;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats of scratch the assigner needs: records + align + sim + candidates + normalisers + partials
+int y3d_tal3d_scratch_floats(int B, int n, int A, int topk) {
+  long blocks = ((long)B * A + 255) / 256;
+  long v = (long)B * n * GTW + 2L * B * n * A + (long)B * n * topk + 2L * B * n + 2 * blocks + 8;
+  return v < (1L << 31) ? (int)v : -1;
+}
+
+static int fill_levels(Levels& L, int dtype, int nl, const void* const* maps, const int64_t* psw, void* const* grads, const int64_t* gsw,
+                       const int* H, const int* W, const float* strides, int B, int nc, int no) {
+  Y3D_CHECK(nl >= 1 && nl <= MAXL, "tal3d: 1..%d levels", MAXL);
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "tal3d: bad dtype");
+  Y3D_CHECK(nc >= 1 && nc <= 5 && no == nc + 35, "tal3d: nc in 1..5 and no == nc + 35");
+  int a0 = 0;
+  for (int i = 0; i < nl; ++i) {
+    L.map[i] = maps[i]; L.psw[i] = psw[i];
+    L.grad[i] = grads ? grads[i] : nullptr; L.gsw[i] = gsw ? gsw[i] : 0;
+    L.H[i] = H[i]; L.W[i] = W[i]; L.a0[i] = a0; L.stride[i] = strides[i];
+    a0 += H[i] * W[i];
+  }
+  for (int i = nl; i < MAXL; ++i) { L.map[i] = nullptr; L.grad[i] = nullptr; L.psw[i] = L.gsw[i] = 0; L.H[i] = L.W[i] = 1; L.a0[i] = a0; L.stride[i] = 1.f; }
+  L.nl = nl; L.A = a0; L.B = B; L.nc = nc; L.no = no;
+  return Y3D_OK;
+}
+
+int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
+                     int B, int nc, const float* gt, int n, const float* calib, const float* mean_sizes, int topk, float alpha,
+                     float beta, float gamma, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
+                     void* stream) {
+  Levels L;
+  if (fill_levels(L, dtype, nl, maps, psw, nullptr, nullptr, H, W, strides, B, nc, nc + 35)) return Y3D_ERR_INVALID;
+  Y3D_CHECK(n >= 1 && n <= 64, "tal3d_assign: 1..64 ground-truth boxes per image (got %d)", n);
+  Y3D_CHECK(topk >= 1 && topk <= 16, "tal3d_assign: topk in 1..16");
+  hipStream_t st = (hipStream_t)stream;
+  const int A = L.A;
+  float* rec = scratch;
+  float* align = rec + (long)B * n * GTW;
+  float* sim = align + (long)B * n * A;
+  int* cand = (int*)(sim + (long)B * n * A);
+  unsigned* pa = (unsigned*)(cand + (long)B * n * topk);
+  unsigned* po = pa + (long)B * n;
+  float* part = (float*)(po + (long)B * n);
+  hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st);
+  hipLaunchKernelGGL(gt_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, calib, mean_sizes, rec, B, n, nc);
+  dim3 gm(cdiv(A, 256), B);
+  size_t sm = (size_t)n * GTW * sizeof(float);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma);
+  else hipLaunchKernelGGL(metric_kernel<float>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma);
+  hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), 0, st, align, rec, cand, L, n, topk);
+  int nblk = cdiv((long)B * A, 256);
+  hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, sim, fg_mask, target_gt_idx, pa, po, B, n, A, topk);
+  hipLaunchKernelGGL(scores_kernel, dim3(nblk), dim3(256), 0, st, fg_mask, target_gt_idx, align, rec, pa, po, target_scores, part, B, n, A, nc, 1e-9f);
+  hipLaunchKernelGGL(scal_kernel, dim3(1), dim3(64), 0, st, part, nblk, scal);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, void* const* grads, const int64_t* gsw, const int* H,
+               const int* W, const float* strides, int B, int nc, const float* gt, int n, const uint8_t* fg_mask,
+               const int* target_gt_idx, const float* target_scores, const float* scal, float w_loss2d, float w_cls, float w_depth,
+               float w_offset3d, float w_size3d, float w_heading, float grad_scale, float* partials, float* items, void* stream) {
+  Levels L;
+  if (fill_levels(L, dtype, nl, maps, psw, grads, gsw, H, W, strides, B, nc, nc + 35)) return Y3D_ERR_INVALID;
+  LossW w{w_loss2d, w_cls, w_depth, w_offset3d, w_size3d, w_heading};
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = cdiv((long)B * L.A, 256);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(loss_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
+  else hipLaunchKernelGGL(loss_kernel<float>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partials, nblk, items);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

@@ -5,10 +5,10 @@ DDDetectionLoss :774; utils/tal.py: TaskAlignedAssigner :19, TaskAlignedAssigner
 utils/keypoint_utils.py; utils/metrics.py:78 bbox_iou).  All arithmetic is fp32 (the reference runs these
 under autocast's fp32 policy), on the tensors' own device.
 
-ROUND-1 STATUS: this file expresses K13-K17 of SURVEY §2.3 with torch *device* ops (HBM-bound, <2 % of
-the step); the fused HIP assigner / loss kernels (tal.hip / loss.hip) replace these bodies behind the same
-class interface — see DESIGN.md "what is not yet hand-written".  Tie rule of the top-k is pinned to
-lowest-index-first.
+The 3D training loss (DetectLoss3d / DDDetectionLoss: assignment + six loss terms + gradient wrt the head maps) runs on the
+fused HIP kernels of csrc/tal_loss3d.hip (`Loss3dFn`).  The torch-op classes below (`TaskAlignedAssigner*`, `v8DetectionLoss`)
+express the same algorithms with torch *device* ops; they serve the 2D (config C1) loss, which has no HIP kernel yet, and the
+GPU tests that hold the HIP assigner to them.  Tie rule of the top-k is pinned to lowest-index-first.
 """
 from __future__ import annotations
 
@@ -17,6 +17,10 @@ import math
 import torch
 import torch.nn.functional as F
 
+import ctypes
+
+from . import ops
+from ._lib import Y3DError, lib
 from .modules import make_anchors
 
 
@@ -203,6 +207,64 @@ def _flatten_maps(feats):
     return torch.cat([f.permute(0, 2, 3, 1).reshape(B, -1, no) for f in feats], 1).float()
 
 
+class Loss3dFn(torch.autograd.Function):
+    """One head set: task-aligned assignment (no grad) + the six 3D loss terms + d(sum of terms)/d(head maps), on the fused HIP
+    kernels.  apply(cfg, gt(B,n,17), calib, mean_sizes, *maps) -> (sum_of_items, items[6], fg_mask, target_gt_idx, target_scores)."""
+
+    @staticmethod
+    def forward(ctx, cfg, gt, calib, mean_sizes, *maps):
+        L = lib()
+        strides, nc, topk, alpha, beta, gamma, w = cfg
+        dtype = maps[0].dtype
+        dt = ops.code(dtype)
+        st = ops.stream()
+        dev = maps[0].device
+        nl = len(maps)
+        for m in maps:
+            if not (m.is_cuda and ops.px_dense(m)):
+                raise Y3DError("Loss3dFn: head maps must be pixel-dense NHWC tensors on a HIP device")
+        B, no = maps[0].shape[:2]
+        Hs = [m.shape[2] for m in maps]
+        Ws = [m.shape[3] for m in maps]
+        A = sum(h * w_ for h, w_ in zip(Hs, Ws))
+        n = gt.shape[1]
+        gt = gt.float().contiguous()
+        calib = calib.float().contiguous()
+        mean_sizes = mean_sizes.float().contiguous()
+        grads = [ops.nhwc_empty(B, no, h, w_, dtype, dev) for h, w_ in zip(Hs, Ws)]
+        PV = ctypes.c_void_p * nl
+        c_maps = PV(*[m.data_ptr() for m in maps])
+        c_grads = PV(*[g.data_ptr() for g in grads])
+        c_psw = (ctypes.c_int64 * nl)(*[m.stride(3) for m in maps])
+        c_gsw = (ctypes.c_int64 * nl)(*[no] * nl)
+        c_H, c_W = (ctypes.c_int * nl)(*Hs), (ctypes.c_int * nl)(*Ws)
+        c_st = (ctypes.c_float * nl)(*strides)
+        nsc = L.tal3d_scratch_floats(B, n, A, topk)
+        if nsc < 0:
+            raise Y3DError("Loss3dFn: assignment scratch exceeds 2^31 floats")
+        scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
+        fg = torch.empty(B, A, dtype=torch.uint8, device=dev)
+        gi = torch.empty(B, A, dtype=torch.int32, device=dev)
+        ts = torch.empty(B, A, nc, dtype=torch.float32, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        L.tal3d_assign(dt, nl, c_maps, c_psw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, calib.data_ptr(), mean_sizes.data_ptr(), topk,
+                       alpha, beta, gamma, scratch.data_ptr(), fg.data_ptr(), gi.data_ptr(), ts.data_ptr(), scal.data_ptr(), st)
+        nblk = (B * A + 255) // 256
+        part = torch.empty(nblk * 6, dtype=torch.float32, device=dev)
+        items = torch.empty(6, dtype=torch.float32, device=dev)
+        L.loss3d(dt, nl, c_maps, c_psw, c_grads, c_gsw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, fg.data_ptr(), gi.data_ptr(), ts.data_ptr(),
+                 scal.data_ptr(), w[0], w[1], w[2], w[3], w[4], w[5], 1.0, part.data_ptr(), items.data_ptr(), st)
+        ctx.save_for_backward(*grads)
+        total = items.sum()
+        ctx.mark_non_differentiable(items, fg, gi, ts)
+        return total, items, fg, gi, ts
+
+    @staticmethod
+    def backward(ctx, d_total, *unused):
+        grads = ctx.saved_tensors
+        return (None, None, None, None, *[g * d_total.to(g.dtype) for g in grads])
+
+
 class DDDetectionLoss:
     """utils/loss.py:774-963"""
 
@@ -221,49 +283,24 @@ class DDDetectionLoss:
     def __call__(self, preds, batch, embeddings=None):
         feats = preds[1] if isinstance(preds, tuple) else preds
         dev = feats[0].device
+        if not feats[0].is_cuda:
+            raise Y3DError("the 3D loss runs on the HIP kernels of tal_loss3d.hip: head maps must live on a HIP device (no CPU fallback)")
         B = feats[0].shape[0]
-        cat = _flatten_maps(feats)
-        sc, o2d, s2d, o3d, s3d, hd, dep, dun = cat.split((self.nc, 2, 2, 2, 3, 24, 1, 1), -1)
-        pred_2d = torch.cat((o2d, s2d), -1)
-        pred_3d = torch.cat((o3d, s3d, hd, dep, dun), -1)
         H, W = feats[0].shape[2:]
         imgsz = torch.tensor([H, W], dtype=torch.float32, device=dev) * self.stride[0]
-        anc, st = make_anchors([f.shape[2:] for f in feats], self.stride, dev)
         rows = torch.cat([batch[k].to(dev).float().view(batch[k].shape[0], -1) for k in
                           ("batch_idx", "cls", "bboxes", "center_2d", "size_2d", "center_3d", "size_3d", "depth", "heading_bin", "heading_res")], 1)
         g = _pad_targets(rows, B, 17, imgsz[[1, 0, 1, 0]])
-        loss = torch.zeros(6, device=dev)
         if g.shape[1] == 0:
+            loss = torch.zeros(6, device=dev)
             return loss.sum() * B, loss  # reference: graph-less zeros (loss.py:873-877); callers skip the step
-        gts = g.split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)
-        mask_gt = (gts[1].sum(2, keepdim=True) > 0).float()
-        centers = anc + pred_2d[..., :2]
-        pb = torch.cat((centers - pred_2d[..., 2:] / 2, centers + pred_2d[..., 2:] / 2), -1) * st
-        targets, fg, gt_idx, _, _ = self.assigner(sc.detach().sigmoid(), pb.detach(), pred_3d.detach(), anc * st, gts, mask_gt, st,
-                                                  batch["calib"].to(dev).float(), batch["mean_sizes"].to(dev).float())
-        _, t_sc, t_c2, t_s2, t_c3, t_s3, t_d, t_hb, t_hr = targets
-        tss = t_sc.sum().clamp(min=1)
-        anc_px = anc * st
         h = self.hyp
-        p2 = (pred_2d * st)[fg]
-        off_l = F.l1_loss(p2[..., :2], (t_c2 - anc_px)[fg], reduction="mean")
-        siz_l = F.l1_loss(p2[..., 2:], t_s2[fg], reduction="mean")
-        l0 = (siz_l + off_l) / tss * h.loss2d
-        l1 = F.binary_cross_entropy_with_logits(sc, t_sc, reduction="none").sum() / tss * h.cls
-        p3 = pred_3d[fg]
-        pd, pu = p3[..., -2], p3[..., -1]
-        td = t_d[fg].squeeze(-1)
-        l2 = (1.4142 * torch.exp(-0.5 * pu) * (pd - td).abs() + 0.5 * pu).sum() / tss * h.depth
-        l3 = F.l1_loss((pred_3d[..., :2] * st)[fg], (t_c3 - anc_px)[fg], reduction="mean") / tss * h.offset3d
-        l4 = F.l1_loss(p3[..., 2:5], t_s3[fg], reduction="sum") / tss * h.size3d
-        ph = p3[..., 5:29]
-        tb = t_hb[fg].view(-1).long()
-        ce = F.cross_entropy(ph[..., :12], tb, reduction="sum")
-        reg = F.l1_loss(ph[..., 12:].gather(1, tb.view(-1, 1)).squeeze(1), t_hr[fg].view(-1), reduction="sum")
-        l5 = (ce + reg) / tss * h.heading
-        loss = torch.stack((l0, l1, l2, l3, l4, l5))
-        self.last_assignment = (fg, gt_idx)
-        return loss.sum() * B, loss
+        cfg = (self.stride[: len(feats)], self.nc, self.assigner.topk, float(h.tal_alpha), float(h.tal_beta), float(h.tal_gamma),
+               (float(h.loss2d), float(h.cls), float(h.depth), float(h.offset3d), float(h.size3d), float(h.heading)))
+        maps = [f if f.dtype == ops.compute_dtype() else f.to(ops.compute_dtype()) for f in feats]
+        total, items, fg, gt_idx, t_sc = Loss3dFn.apply(cfg, g, batch["calib"].to(dev), batch["mean_sizes"].to(dev), *maps)
+        self.last_assignment = (fg.bool(), gt_idx.long(), t_sc)
+        return total * B, items
 
 
 class DetectLoss3d:

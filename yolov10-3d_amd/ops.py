@@ -163,7 +163,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
                        part.data_ptr() if training else None, st)
     else:
-        nblk = L.conv_stat_blocks(B, Ho, Wo)
+        nblk = L.conv2d_stat_rows(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)
         if training:
             part = _f32(nblk * Cout * 2, dev)
         Cg_pad = Cin_k // g
