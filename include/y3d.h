@@ -59,8 +59,13 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
 int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
                         const void* w_packed_dgrad, void* dx, int64_t xsw, int H, int W, int Cin, int groups, int kh, int kw,
                         int stride, int pad, void* stream);
-/* split-K factor the weight gradient wants; slab must hold nsplit*Cout*kh*kw*Cin_g floats */
+/* split-K factor of the generic weight-gradient kernel; slab must hold nsplit*Cout*kh*kw*Cin_g floats */
 int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_g, int groups, int kh, int kw);
+/* split-K factor y3d_conv2d_bwd_weight expects for this geometry (it dispatches 3x3 s1 p1 bf16 convs with 64-channel slabs to
+ * the resident-tile weight-gradient kernel); same slab sizing rule */
+int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
+/* testing / A-B knob: 0 routes every convolution through the generic implicit-GEMM kernels; returns the previous value */
+int y3d_set_tile_kernels(int enable);
 /* grad_oihw (+)= dL/dw.  Cin may be channel-padded (stem): only the first Cin_real channels are written. */
 int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
                           int Cin_real, const void* dy, int64_t dsw, int Ho, int Wo, int Cout, int groups, int kh, int kw,

@@ -441,3 +441,30 @@ def test_tal3d_hip_on_assigner_fixture_scale():
         mism = int((fg != fg_t).sum()) + int((gi != gi_t).sum())
         assert mism == 0, f"topk={topk}: {mism} anchors differ"
         check(ts, targets[1], 1e-4, "target_scores")
+
+
+@pytest.mark.parametrize("case", [(128, 256, 3, 1, 1, 32, 80, 2), (64, 96, 3, 1, 1, 16, 40, 2), (128, 128, 3, 1, 1, 20, 20, 3),
+                                  (256, 256, 3, 1, 4, 16, 16, 2), (2048, 2048, 3, 1, 16, 40, 40, 2)])
+def test_tile_kernels_agree_with_generic_kernels(case):
+    """A/B inside one process: the resident-tile kernels (conv3x3_tile / conv3x3_wgrad_tile) and the generic implicit-GEMM
+    kernels compute the same bf16 products with fp32 accumulation, so forward, dx and dW must agree to accumulation-order noise."""
+    c1, c2, k, s, g, H, W, B = case
+    y3d.set_compute_dtype(torch.bfloat16)
+    L = y3d.lib()
+    torch.manual_seed(3)
+    mod = M.Conv(c1, c2, k, s, None, g).to(DEV).train()
+    x = torch.randn(B, c1, H, W, device=DEV)
+    r = torch.randn(B, c2, H, W, device=DEV)
+    outs = {}
+    for enable in (1, 0):
+        old = L.set_tile_kernels(enable)
+        try:
+            mod.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            y = mod(xi)
+            (y.float() * r).sum().backward()
+            outs[enable] = (y.detach().float(), xi.grad.float(), mod.conv.weight.grad.clone())
+        finally:
+            L.set_tile_kernels(old)
+    for a, b, what, tol in zip(outs[1], outs[0], ("y", "dx", "dW"), (2e-2, 2e-2, 2e-3)):
+        check(a, b, tol, f"tile vs generic {what}")

@@ -55,7 +55,7 @@ def main():
             L.pack_weight_dgrad(dt, w.data_ptr(), wpd.data_ptr(), Cout, Cin // g, g, k, k, st)
             dx = ops.nhwc_empty(B, Cin, H, W, dtype, dev)
             dsb, dsh, dsw = ops.s3(dy)
-            ns = L.conv2d_wgrad_splits(dt, B, Ho, Wo, Cout, Cin // g, g, k, k)
+            ns = L.conv2d_wgrad_plan(dt, B, H, W, Cin, Cout, g, k, k, s, p)
             slab = torch.empty(ns * Cout * k * k * (Cin // g), device=dev)
             dW = torch.empty_like(w)
             runs.append(("dgrad", lambda: L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, W, Cin, g, k, k, s, p, st)))

@@ -519,12 +519,34 @@ int y3d_tile_height(int dtype, int H, int W, int Cg, int kh, int kw, int stride,
 int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G,
                             const void* w, int Ktot, void* y, long ysw, float* part, int flip, void* stream);
 
+// conv3x3_wgrad_tile.hip
+int y3d_wgrad_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad);
+int y3d_wgrad_tile_splits(int th, int B, int H, int W, int Cg, int Cn, int G);
+int y3d_conv3x3_wgrad_tile_launch(int th, const void* x, long xsb, long xsh, long xsw, const void* dy, long dsw, int B, int H, int W, int Cg,
+                                  int Cn, int G, float* slab, int nsplit, void* stream);
+
+static int g_tile_kernels = 1;
+extern "C" int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_g, int groups, int kh, int kw);
+
 extern "C" {
+
+int y3d_set_tile_kernels(int enable) {
+  int old = g_tile_kernels;
+  g_tile_kernels = enable ? 1 : 0;
+  return old;
+}
 
 int y3d_conv_stat_blocks(int B, int Ho, int Wo) { return cdiv((long)B * Ho * Wo, 128); }
 
+int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
+  int th = (g_tile_kernels && groups > 0) ? y3d_wgrad_tile_height(dtype, H, W, Cin / groups, Cout / groups, kh, kw, stride, pad) : 0;
+  if (th) return y3d_wgrad_tile_splits(th, B, H, W, Cin / groups, Cout / groups, groups);
+  int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  return y3d_conv2d_wgrad_splits(dtype, B, Ho, Wo, Cout, Cin / groups, groups, kh, kw);
+}
+
 int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
-  int th = groups > 0 ? y3d_tile_height(dtype, H, W, Cin / groups, kh, kw, stride, pad) : 0;
+  int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, H, W, Cin / groups, kh, kw, stride, pad) : 0;
   if (th) return B * (H / th) * cdiv(W, 16);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   return cdiv((long)B * Ho * Wo, 128);
@@ -591,7 +613,7 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
   p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
-  if (!bias) {
+  if (!bias && g_tile_kernels) {
     int th = y3d_tile_height(dtype, H, W, p.Cg, kh, kw, stride, pad);
     if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, stream);
   }
@@ -617,7 +639,7 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   p.Cg = Cout / groups; p.Cn = Cin / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = y3d_conv_kpad(dtype, p.Ktot); p.M = B * H * W;
-  {
+  if (g_tile_kernels) {
     // a 3x3 s1 p1 data gradient is the same conv on dy with flipped taps (Ho == H, Wo == W)
     int th = y3d_tile_height(dtype, Ho, Wo, p.Cg, kh, kw, stride, pad);
     if (th && Ho == H && Wo == W)
@@ -659,8 +681,20 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.M = B * Ho * Wo; p.nsplit = nsplit;
   p.chunk_px = cdiv(cdiv(p.M, nsplit), bpk) * bpk;
-  dim3 grid(cdiv(p.Ktot, 128), cdiv(p.Cn, 128), groups * nsplit);
   hipStream_t st = (hipStream_t)stream;
+  {
+    int th = g_tile_kernels ? y3d_wgrad_tile_height(dtype, H, W, p.Cg, p.Cn, kh, kw, stride, pad) : 0;
+    if (th && Cin_real == Cin) {
+      Y3D_CHECK(nsplit == y3d_wgrad_tile_splits(th, B, H, W, p.Cg, p.Cn, groups), "conv2d_bwd_weight: nsplit must come from y3d_conv2d_wgrad_plan");
+      int rc = y3d_conv3x3_wgrad_tile_launch(th, x, xsb, xsh, xsw, dy, dsw, B, H, W, p.Cg, p.Cn, groups, slab, nsplit, stream);
+      if (rc) return rc;
+      long n2 = (long)Cout * kh * kw * p.Cg;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, st, slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, p.Cg, accumulate);
+      Y3D_LAUNCH_CHECK();
+      return Y3D_OK;
+    }
+  }
+  dim3 grid(cdiv(p.Ktot, 128), cdiv(p.Cn, 128), groups * nsplit);
   size_t sm = dtype == Y3D_BF16 ? 4 * 64 * (256 + 32) : 4 * 32 * (512 + 64);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), sm, st, p);
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), sm, st, p);

@@ -246,7 +246,7 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
             _timed(("conv_dgrad", dt, B, H, W, Cin, co, k, s, g),
                    lambda: L.conv2d_bwd_data(dt, dy.data_ptr() + lo * esz, dsb, dsh, dsw, B, Ho, Wo, co, wpd.data_ptr(), dx.data_ptr(), Cin, H, W,
                                              Cin, g, k, k, s, p, st))
-        ns = L.conv2d_wgrad_splits(dt, B, Ho, Wo, Cout, Cin_k // g, g, k, k)
+        ns = L.conv2d_wgrad_plan(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)
         slab = _f32(ns * Cout * k * k * (Cin_k // g), dev)
         _timed(("conv_wgrad", dt, B, H, W, Cin_k, Cout, k, s, g),
                lambda: L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k,
