@@ -24,10 +24,13 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--no-tile", action="store_true", help="route everything through the generic implicit-GEMM kernels")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     y3d.set_compute_dtype(dtype)
     L = y3d.lib()
+    if a.no_tile:
+        L.set_tile_kernels(0)
     dt = ops.code(dtype)
     dev = "cuda"
     for i, (B, H, W, Cin, Cout, k, s, g) in enumerate(SHAPES):

@@ -67,11 +67,13 @@ __device__ __forceinline__ float silu_grad_f(float u) {
   return s * (1.f + u * (1.f - s));
 }
 
-__device__ __forceinline__ float wave_xor_sum16(float v) {  // sum over the 16 lanes sharing lane>>4
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the total.
+// Four v_add_f32 with DPP operand swizzles (quad_perm xor-1, xor-2, row_half_mirror, row_mirror) - no LDS crossbar round trips.
+__device__ __forceinline__ float wave_xor_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
   return v;
 }
 

@@ -40,13 +40,14 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
   constexpr int HWD = 18;
   constexpr int NPIX = (TH + 2) * HWD;
   constexpr int HCH = NPIX * 8;            // 16-byte chunks of one halo slab
-  constexpr int HR = (HCH + NT - 1) / NT;  // DMA rounds per halo slab (<= 9)
-  constexpr int HBYTES = HR * NT * 16;
+  constexpr int HR = (HCH + NT - 1) / NT;  // DMA rounds per halo slab
+  constexpr int HBYTES = HCH * 16;         // exact: lanes past the end of the last round are masked off
   constexpr int WR = 1024 / NT;            // DMA rounds per 128 x 128 B weight tile
-  static_assert(HR <= 9, "halo rounds are spread over the nine taps");
+  constexpr int TPS = TH == 16 ? 2 : 1;    // filter taps per barrier: 64 MFMAs per wave between barriers at TH=16
+  constexpr int WBYTES = TPS * 16384;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sH = smem;               // [2][HBYTES]
-  char* sW = smem + 2 * HBYTES;  // [2][16 KB]
+  char* sW = smem + 2 * HBYTES;  // [2][TPS][16 KB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wp = wave >> 1, wc = wave & 1;
@@ -86,13 +87,14 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
     int n = chunk >> 3, s = chunk & 7;
     wsrc[rd] = (c0 + n < p.Cn) ? Wt + ((long)(g * p.Cn + c0 + n)) * p.Ktot + ((s ^ (n & 7)) * CE) : nullptr;
   }
-  auto issue_w = [&](int slab, int tap, int buf) {
+  auto issue_w = [&](int lin, char* dstbase) {  // lin = slab * 9 + tap
+    const int slab = lin / 9, tap = lin - slab * 9;
     const long off = (long)(p.flip ? 8 - tap : tap) * p.Cg + (long)slab * CSE;
 #pragma unroll
     for (int rd = 0; rd < WR; ++rd) {
       const T* src = wsrc[rd] ? wsrc[rd] + off : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sW + buf * 16384 + (rd * NT + wave * 64) * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dstbase + (rd * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
   auto issue_h = [&](int slab, int buf, int rd) {
@@ -111,19 +113,24 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
     for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nslab = p.Cg / CSE;
+  const int S = nslab * 9;  // linear (slab, tap) steps
 #pragma unroll
   for (int rd = 0; rd < HR; ++rd) issue_h(0, 0, rd);
-  issue_w(0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TPS; ++t)
+    if (t < S) issue_w(t, sW + t * 16384);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // Fragments are double buffered by hand: while the 16 MFMAs of one K sub-step run, the LDS reads of the next sub-step are
-  // already in flight; the halo (pixel) fragments of the NEXT tap are prefetched across the barrier too (the halo slab does not
-  // change within a slab), only the four weight fragments of a tap's first sub-step wait for the barrier that publishes the DMA.
+  // already in flight (also across taps and, for the halo operand, across the barrier: the halo slab is stable within a slab).
+  // Only the four weight fragments of a stage's first sub-step wait for the barrier that publishes the DMA.
   constexpr int KS = Frag<T>::KSUB;
   typename Frag<T>::type fb[2][4], fa[2][4];
-  auto load_b = [&](typename Frag<T>::type* dst, const char* hb, int tap, int ks) {
+  auto load_b = [&](typename Frag<T>::type* dst, int lin, int ks) {
+    const int slab = lin / 9, tap = lin - slab * 9;
     const int r = tap / 3, q = tap - r * 3;
+    const char* hb = sH + (slab & 1) * HBYTES;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) dst[pt] = Frag<T>::load(hb, (4 * wp + pt + r) * HWD + q, ks, lane);
   };
@@ -131,40 +138,57 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) dst[ct] = Frag<T>::load(wb, wc * 64 + ct * 16, ks, lane);
   };
-  load_b(fb[0], sH, 0, 0);
-  int st = 0;
-  for (int slab = 0; slab < nslab; ++slab) {
-    const char* hb = sH + (slab & 1) * HBYTES;
-    for (int tap = 0; tap < 9; ++tap, ++st) {
-      // prefetch: next weight tile, and one DMA round of the next slab's halo per tap
-      if (tap < 8) issue_w(slab, tap + 1, (st + 1) & 1);
-      else if (slab + 1 < nslab) issue_w(slab + 1, 0, (st + 1) & 1);
-      if (slab + 1 < nslab && tap < HR) issue_h(slab + 1, (slab + 1) & 1, tap);
-      const char* wb = sW + (st & 1) * 16384;
-      load_a(fa[0], wb, 0);
+  load_b(fb[0], 0, 0);
+  int hslab = 0, hrd = 0;  // slab whose halo is being streamed in, next DMA round
+  for (int s0 = 0, stg = 0; s0 < S; s0 += TPS, ++stg) {
+    // prefetch the next stage's weight tiles; bring in the next slab's halo as soon as its buffer is free
+    char* wnext = sW + ((stg + 1) & 1) * WBYTES;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
+    for (int t = 0; t < TPS; ++t)
+      if (s0 + TPS + t < S) issue_w(s0 + TPS + t, wnext + t * 16384);
+    {
+      // every tap of this stage lies in slab >= k, so slab k-1's halo buffer is free: stream slab k+1's halo into it, a few
+      // DMA rounds per stage (all rounds have landed at least one stage before the first tap of slab k+1 is prefetched)
+      const int k = s0 / 9;
+      if (k + 1 < nslab) {
+        if (hslab != k + 1) { hslab = k + 1; hrd = 0; }
+        constexpr int RPS = TPS == 2 ? (HR + 2) / 3 : (HR + 5) / 6;
+#pragma unroll
+        for (int rd = 0; rd < HR; ++rd)
+          if (rd >= hrd && rd < hrd + RPS) issue_h(k + 1, (k + 1) & 1, rd);
+        hrd += RPS;
+      }
+    }
+    const char* wb = sW + (stg & 1) * WBYTES;
+    load_a(fa[0], wb, 0);
+#pragma unroll
+    for (int step = 0; step < TPS * KS; ++step) {
+      const int t = step / KS, ks = step - t * KS;
+      const int cur = step & 1, nxt = cur ^ 1;
+      if (s0 + t < S) {  // uniform: the last stage may hold fewer taps
         if (ks + 1 < KS) {
-          load_b(fb[nxt], hb, tap, ks + 1);
-          load_a(fa[nxt], wb, ks + 1);
-        } else if (tap < 8) {
-          load_b(fb[nxt], hb, tap + 1, 0);
-        } else if (slab + 1 < nslab) {
-          load_b(fb[nxt], sH + ((slab + 1) & 1) * HBYTES, 0, 0);  // next slab's halo: its last DMA round landed <= 2 taps ago
+          load_b(fb[nxt], s0 + t, ks + 1);
+          load_a(fa[nxt], wb + t * 16384, ks + 1);
+        } else if (t + 1 < TPS) {
+          if (s0 + t + 1 < S) {
+            load_b(fb[nxt], s0 + t + 1, 0);
+            load_a(fa[nxt], wb + (t + 1) * 16384, 0);
+          }
+        } else if (s0 + TPS < S) {
+          load_b(fb[nxt], s0 + TPS, 0);  // first sub-step of the next stage: halo operand only
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
           for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = Frag<T>::mma(fa[cur][ct], fb[cur][pt], acc[ct][pt]);
       }
-      if (KS & 1) {  // keep "next tap, sub-step 0" in buffer 0 (never taken: KSUB is 2 or 8)
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) fb[0][pt] = fb[1][pt];
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
     }
+    if ((TPS * KS) & 1) {
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) fb[0][pt] = fb[1][pt];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 
   // ---- epilogue: store, optional BN partial sums over the valid pixels -----------------------------------------------------
@@ -237,11 +261,10 @@ template <typename T, int TH>
 int launch_tile(const C3P& p, hipStream_t st) {
   constexpr int NW = TH / 2, NT = NW * 64;
   constexpr int HCH = (TH + 2) * 18 * 8;
-  constexpr int HR = (HCH + NT - 1) / NT;
-  size_t sm = 2 * (size_t)HR * NT * 16 + 2 * 16384;
+  size_t sm = 2 * (size_t)HCH * 16 + 2 * (size_t)(TH == 16 ? 2 : 1) * 16384;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    (void)hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     attr_set = true;
   }
   dim3 grid(p.B * p.nty * p.ntx * p.ntc, 1, p.G);
@@ -260,7 +283,8 @@ int y3d_tile_height(int dtype, int H, int W, int Cg, int kh, int kw, int stride,
   if (W < 8) return 0;
   if (H % 16 == 0) return 16;
   if (H % 8 == 0) return 8;
-  if (H % 4 == 0) return 4;
+  // TH = 4 (two waves per workgroup) is built and tested but measured slower than the generic implicit GEMM on 20x20 maps
+  // (262 vs 691 TFLOP/s, 512->2048, B=32): too few waves per CU to hide the DMA / LDS latency
   return 0;
 }
 
