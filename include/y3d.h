@@ -147,6 +147,16 @@ int y3d_proj_blocks(int64_t P);
 int y3d_proj_bwd_weight(int dtype, const void* x, int64_t xsw, const void* dy, int64_t dsw, float* slab, float* bias_slab,
                         float* grad_w, float* grad_b, int accumulate, int64_t P, int Cin, int Cout, void* stream);
 int y3d_slab_reduce(const float* slab, float* out, int nblk, int64_t n, int accumulate, void* stream);
+/* the nb (<= 16) final projections of one head level in ONE launch (proj_group.hip): branch j reads channels
+ * [xoff[j], xoff[j]+cin) of x and writes couts[j] channels at the running output offset (the torch.cat of head.py:742).
+ * w / b / dw / db: host arrays of nb device pointers.  slab: y3d_proj_group_blocks(P)*sum(couts)*cin floats, bslab: ...*sum(couts) */
+int y3d_proj_group_fwd(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const float* const* w,
+                       const float* const* b, const int* couts, void* y, int64_t ysw, int64_t P, void* stream);
+int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t dsw, const int* xoff, const float* const* w,
+                            const int* couts, void* dx, int64_t xsw, int64_t P, void* stream);
+int y3d_proj_group_blocks(int64_t P);
+int y3d_proj_group_bwd_weight(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
+                              const int* couts, float* slab, float* bslab, float* const* dw, float* const* db, int64_t P, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PSA attention core (attn.hip) — Attention.forward block.py:785-797

@@ -1,0 +1,255 @@
+// The 16 final projections of one head level (8 branches x 2 head sets: nn.Conv2d(mid, out, 1) + bias, head.py:637, followed by the
+// torch.cat of head.py:742) as ONE launch per direction: blockIdx.z walks the branches, each reading its channel slice of the
+// stacked feature tensor and writing its channel slice of the (B, sum(out), H, W) map.  Small-N work: VALU, HBM-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXB = 16;
+
+struct ProjG {
+  const float* w[MAXB];   // [cout][cin] fp32
+  const float* b[MAXB];   // [cout]
+  float* dw[MAXB];
+  float* db[MAXB];
+  int xoff[MAXB];         // channel offset of the branch's input slice inside x
+  int ooff[MAXB];         // channel offset of the branch's outputs inside y / dy
+  int cout[MAXB];
+  int nb, cin;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void projg_fwd_kernel(ProjG g, const T* __restrict__ x, long xsw, T* __restrict__ y, long ysw, long P) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int CN = 24;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sw = (float*)smem;
+  const int br = blockIdx.z, Cin = g.cin, Cout = g.cout[br];
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = g.w[br][i];
+  __syncthreads();
+  const int sub = threadIdx.x & 7;
+  const int cpr = Cin / CE;
+  long px = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const T* xp = x + g.xoff[br];
+  float acc[CN];
+#pragma unroll
+  for (int o = 0; o < CN; ++o) acc[o] = 0.f;
+  if (px < P) {
+    for (int ch = sub; ch < cpr; ch += 8) {
+      float v[CE];
+      Chunk<T>::unpack(*(const uint4*)(xp + px * xsw + ch * CE), v);
+#pragma unroll
+      for (int o = 0; o < CN; ++o)
+        if (o < Cout) {
+          const float* wr = sw + o * Cin + ch * CE;
+#pragma unroll
+          for (int j = 0; j < CE; ++j) acc[o] += v[j] * wr[j];
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CN; ++o)
+    if (o < Cout) {  // uniform
+      acc[o] += __shfl_xor(acc[o], 1);
+      acc[o] += __shfl_xor(acc[o], 2);
+      acc[o] += __shfl_xor(acc[o], 4);
+    }
+  if (px < P && sub == 0) {
+    T* yp = y + px * ysw + g.ooff[br];
+#pragma unroll
+    for (int o = 0; o < CN; ++o)
+      if (o < Cout) TT<T>::st(yp + o, acc[o] + g.b[br][o]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void projg_bwd_data_kernel(ProjG g, const T* __restrict__ dy, long dsw, T* __restrict__ dx, long xsw, long P) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int CN = 24;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sw = (float*)smem;
+  const int br = blockIdx.z, Cin = g.cin, Cout = g.cout[br];
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = g.w[br][i];
+  __syncthreads();
+  const int cpr = Cin / CE;
+  long total = P * cpr;
+  const T* dp = dy + g.ooff[br];
+  T* xp = dx + g.xoff[br];
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long px = idx / cpr;
+    int c = (int)(idx - px * cpr) * CE;
+    float acc[CE];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int o = 0; o < CN; ++o)
+      if (o < Cout) {
+        float d = TT<T>::ld(dp + px * dsw + o);
+        const float* wr = sw + o * Cin + c;
+#pragma unroll
+        for (int j = 0; j < CE; ++j) acc[j] += d * wr[j];
+      }
+    *(uint4*)(xp + px * xsw + c) = Chunk<T>::pack(acc);
+  }
+}
+
+// slab[blk][ooff + co][ci] / bslab[blk][ooff + co]: per-block partial sums over the block's pixel range
+template <typename T>
+__global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T* __restrict__ x, long xsw, const T* __restrict__ dy, long dsw,
+                                                               float* __restrict__ slab, float* __restrict__ bslab, long P, int ctot,
+                                                               int px_per_block) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int CT = 64 / CE;
+  constexpr int PT = 256 / CT;
+  constexpr int OG = 4;
+  __shared__ float sh[PT][64];
+  const int br = blockIdx.z, Cin = g.cin, Cout = g.cout[br];
+  const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+  const int cs = blockIdx.y * 64;
+  const int c = cs + ct * CE;
+  const T* xp = x + g.xoff[br];
+  const T* dp = dy + g.ooff[br];
+  long pbeg = (long)blockIdx.x * px_per_block;
+  long pend = pbeg + px_per_block < P ? pbeg + px_per_block : P;
+  for (int o0 = 0; o0 < Cout; o0 += OG) {
+    float acc[OG][CE], bacc[OG];
+#pragma unroll
+    for (int o = 0; o < OG; ++o) {
+      bacc[o] = 0.f;
+#pragma unroll
+      for (int j = 0; j < CE; ++j) acc[o][j] = 0.f;
+    }
+    if (c < Cin) {
+      for (long px = pbeg + pt; px < pend; px += PT) {
+        float v[CE];
+        Chunk<T>::unpack(*(const uint4*)(xp + px * xsw + c), v);
+#pragma unroll
+        for (int o = 0; o < OG; ++o)
+          if (o0 + o < Cout) {
+            float d = TT<T>::ld(dp + px * dsw + o0 + o);
+            bacc[o] += d;
+#pragma unroll
+            for (int j = 0; j < CE; ++j) acc[o][j] += d * v[j];
+          }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OG; ++o) {
+      if (o0 + o < Cout) {
+#pragma unroll
+        for (int j = 0; j < CE; ++j) sh[pt][ct * CE + j] = acc[o][j];
+        __syncthreads();
+        if (threadIdx.x < 64 && cs + threadIdx.x < Cin) {
+          float a = 0.f;
+          for (int r = 0; r < PT; ++r) a += sh[r][threadIdx.x];
+          slab[((long)blockIdx.x * ctot + g.ooff[br] + o0 + o) * Cin + cs + threadIdx.x] = a;
+        }
+        __syncthreads();
+        if (blockIdx.y == 0) {
+          sh[pt][ct] = bacc[o];
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            float a = 0.f;
+            for (int r = 0; r < PT; ++r) a += sh[r][0];
+            bslab[(long)blockIdx.x * ctot + g.ooff[br] + o0 + o] = a;
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
+// per branch: dw[br][co][ci] = sum_blk slab[blk][ooff+co][ci];  db[br][co] = sum_blk bslab[blk][ooff+co]
+__global__ void projg_reduce_kernel(ProjG g, const float* __restrict__ slab, const float* __restrict__ bslab, int nblk, int ctot) {
+  const int br = blockIdx.y, Cin = g.cin, Cout = g.cout[br];
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < Cout * Cin) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += slab[((long)b * ctot + g.ooff[br]) * Cin + idx];
+    g.dw[br][idx] = s;
+  }
+  if (idx < Cout) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += bslab[(long)b * ctot + g.ooff[br] + idx];
+    g.db[br][idx] = s;
+  }
+}
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+int fill(ProjG& g, int nb, int cin, const float* const* w, const float* const* b, float* const* dw, float* const* db, const int* xoff,
+         const int* couts) {
+  Y3D_CHECK(nb >= 1 && nb <= MAXB, "proj_group: 1..%d branches", MAXB);
+  Y3D_CHECK((size_t)24 * cin * 4 <= 64 * 1024, "proj_group: cin too large for the LDS weight slab");
+  int off = 0;
+  for (int i = 0; i < nb; ++i) {
+    Y3D_CHECK(couts[i] >= 1 && couts[i] <= 24, "proj_group: cout in 1..24");
+    g.w[i] = w[i]; g.b[i] = b ? b[i] : nullptr; g.dw[i] = dw ? dw[i] : nullptr; g.db[i] = db ? db[i] : nullptr;
+    g.xoff[i] = xoff[i]; g.ooff[i] = off; g.cout[i] = couts[i];
+    off += couts[i];
+  }
+  g.nb = nb; g.cin = cin;
+  return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_proj_group_fwd(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const float* const* w,
+                       const float* const* b, const int* couts, void* y, int64_t ysw, int64_t P, void* stream) {
+  ProjG g;
+  int ctot = fill(g, nb, cin, w, b, nullptr, nullptr, xoff, couts);
+  if (ctot < 0) return ctot;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "proj_group_fwd: bad dtype");
+  Y3D_CHECK(cin % (dtype == Y3D_BF16 ? 8 : 4) == 0 && ysw >= ctot, "proj_group_fwd: channel alignment");
+  dim3 grid(cdiv(P, 32), 1, nb);
+  size_t sm = (size_t)24 * cin * 4;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_fwd_kernel<bf16_t>, grid, dim3(256), sm, (hipStream_t)stream, g, (const bf16_t*)x, (long)xsw, (bf16_t*)y, (long)ysw, (long)P);
+  else hipLaunchKernelGGL(projg_fwd_kernel<float>, grid, dim3(256), sm, (hipStream_t)stream, g, (const float*)x, (long)xsw, (float*)y, (long)ysw, (long)P);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t dsw, const int* xoff, const float* const* w,
+                            const int* couts, void* dx, int64_t xsw, int64_t P, void* stream) {
+  ProjG g;
+  int ctot = fill(g, nb, cin, w, nullptr, nullptr, nullptr, xoff, couts);
+  if (ctot < 0) return ctot;
+  long total = P * (cin / (dtype == Y3D_BF16 ? 8 : 4));
+  dim3 grid(ew_grid(total), 1, nb);
+  size_t sm = (size_t)24 * cin * 4;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_bwd_data_kernel<bf16_t>, grid, dim3(256), sm, (hipStream_t)stream, g, (const bf16_t*)dy, (long)dsw, (bf16_t*)dx, (long)xsw, (long)P);
+  else hipLaunchKernelGGL(projg_bwd_data_kernel<float>, grid, dim3(256), sm, (hipStream_t)stream, g, (const float*)dy, (long)dsw, (float*)dx, (long)xsw, (long)P);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_proj_group_blocks(int64_t P) {
+  long n = (P + 1023) / 1024;
+  return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+}
+
+/* slab: blocks * ctot * cin floats, bslab: blocks * ctot floats */
+int y3d_proj_group_bwd_weight(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
+                              const int* couts, float* slab, float* bslab, float* const* dw, float* const* db, int64_t P, void* stream) {
+  ProjG g;
+  const float* dummy[MAXB] = {nullptr};
+  int ctot = fill(g, nb, cin, dummy, nullptr, dw, db, xoff, couts);
+  if (ctot < 0) return ctot;
+  int nblk = y3d_proj_group_blocks(P);
+  int ppb = (int)((P + nblk - 1) / nblk);
+  dim3 grid(nblk, cdiv(cin, 64), nb);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const bf16_t*)x, (long)xsw, (const bf16_t*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb);
+  else hipLaunchKernelGGL(projg_bwd_weight_kernel<float>, grid, dim3(256), 0, st, g, (const float*)x, (long)xsw, (const float*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb);
+  hipLaunchKernelGGL(projg_reduce_kernel, dim3(cdiv(24 * cin, 256), nb), dim3(256), 0, st, g, slab, bslab, nblk, ctot);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

@@ -437,12 +437,13 @@ class HeadProjFn(torch.autograd.Function):
 
 
 class HeadProjSlicesFn(torch.autograd.Function):
-    """Same projections as HeadProjFn, but every branch reads a channel slice [off_j, off_j+cin_j) of ONE stacked feature
-    tensor and the backward writes each branch's input gradient straight into its slice of one gradient tensor
-    (no per-branch narrow()/add round trips through autograd).  args: x_full, offsets, cins, n, w_0.., b_0.."""
+    """Same projections as HeadProjFn, but every branch reads a channel slice [off_j, off_j+cin) of ONE stacked feature
+    tensor, all branches of a level run as ONE launch per direction (proj_group.hip) and the backward writes each branch's
+    input gradient straight into its slice of one gradient tensor.  args: x_full, offsets, cins, n, w_0.., b_0.."""
 
     @staticmethod
     def forward(ctx, x, offsets, cins, n, *args):
+        import ctypes
         L = lib()
         ws, bs = args[:n], args[n:2 * n]
         dtype = _COMPUTE_DTYPE
@@ -452,24 +453,26 @@ class HeadProjSlicesFn(torch.autograd.Function):
         B, Ct, H, W = x.shape
         P = B * H * W
         couts = [w.shape[0] for w in ws]
+        cin = cins[0]
+        assert all(c == cin for c in cins) and n <= 16, "HeadProjSlicesFn: uniform branch width, at most 16 branches"
         tot = sum(couts)
         out = nhwc_empty(B, tot, H, W, dtype, x.device)
-        esz = out.element_size()
         w32 = [w.detach().float().contiguous() for w in ws]
         b32 = [b.detach().float().contiguous() for b in bs]
-        off = 0
-        for xo, ci, w, b, co in zip(offsets, cins, w32, b32, couts):
-            assert co <= 24
-            L.proj_fwd(dt, x.data_ptr() + xo * esz, x.stride(3), w.data_ptr(), b.data_ptr(), out.data_ptr() + off * esz, tot, P, ci, co, st)
-            off += co
-        ctx.meta = (offsets, cins, n, couts, dtype)
+        PV = ctypes.c_void_p * n
+        IA = ctypes.c_int * n
+        c_w, c_b = PV(*[w.data_ptr() for w in w32]), PV(*[b.data_ptr() for b in b32])
+        c_off, c_co = IA(*offsets), IA(*couts)
+        L.proj_group_fwd(dt, n, cin, x.data_ptr(), x.stride(3), c_off, c_w, c_b, c_co, out.data_ptr(), tot, P, st)
+        ctx.meta = (list(offsets), cin, n, couts, dtype)
         ctx.save_for_backward(x, *w32)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        import ctypes
         L = lib()
-        offsets, cins, n, couts, dtype = ctx.meta
+        offsets, cin, n, couts, dtype = ctx.meta
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         dt = code(dtype)
         st = stream()
@@ -478,28 +481,23 @@ class HeadProjSlicesFn(torch.autograd.Function):
         B, Ct, H, W = x.shape
         P = B * H * W
         dev = x.device
-        esz = x.element_size()
-        dsw = dout.stride(3)
-        nb = L.proj_blocks(P)
+        tot = sum(couts)
+        PV = ctypes.c_void_p * n
+        IA = ctypes.c_int * n
+        c_w, c_off, c_co = PV(*[w.data_ptr() for w in ws]), IA(*offsets), IA(*couts)
         dx = None
         if ctx.needs_input_grad[0]:
-            covered = sum(cins) == Ct
             dx = nhwc_empty(B, Ct, H, W, dtype, dev)
-            if not covered:
+            if n * cin != Ct:
                 dx.zero_()
-        dws, dbs, off = [], [], 0
-        slab = _f32(nb * max(co * ci for co, ci in zip(couts, cins)), dev)
-        bslab = _f32(nb * max(couts), dev)
-        for xo, ci, w, co in zip(offsets, cins, ws, couts):
-            if dx is not None:
-                L.proj_bwd_data(dt, dout.data_ptr() + off * esz, dsw, w.data_ptr(), dx.data_ptr() + xo * esz, Ct, P, ci, co, st)
-            dW = torch.empty_like(w)
-            db = _f32(co, dev)
-            L.proj_bwd_weight(dt, x.data_ptr() + xo * esz, x.stride(3), dout.data_ptr() + off * esz, dsw, slab.data_ptr(), bslab.data_ptr(),
-                              dW.data_ptr(), db.data_ptr(), 0, P, ci, co, st)
-            dws.append(dW)
-            dbs.append(db)
-            off += co
+            L.proj_group_bwd_data(dt, n, cin, dout.data_ptr(), dout.stride(3), c_off, c_w, c_co, dx.data_ptr(), Ct, P, st)
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [_f32(co, dev) for co in couts]
+        nb = L.proj_group_blocks(P)
+        slab = _f32(nb * tot * cin, dev)
+        bslab = _f32(nb * tot, dev)
+        L.proj_group_bwd_weight(dt, n, cin, x.data_ptr(), x.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, slab.data_ptr(),
+                                bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]), PV(*[t.data_ptr() for t in dbs]), P, st)
         return (dx, None, None, None, *dws, *dbs)
 
 
