@@ -55,6 +55,11 @@ int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int 
 int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
                    const void* w_packed, const float* bias, void* y, int64_t ysw, int Ho, int Wo, int Cout, int groups,
                    int kh, int kw, int stride, int pad, float* stat_partials, void* stream);
+/* eval-mode Conv in ONE launch: y = act(conv(x, w) * scale[c] + shift[c]) with scale/shift from y3d_bn_eval_scale
+ * (Conv.forward with BatchNorm in eval mode, conv.py:120-122; equals the reference's fuse_conv_and_bn folding, torch_utils.py:171-198) */
+int y3d_conv2d_fwd_affine(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                          const void* w_packed, const float* scale, const float* shift, int act, void* y, int64_t ysw, int Ho, int Wo,
+                          int Cout, int groups, int kh, int kw, int stride, int pad, void* stream);
 /* dx = conv_transpose(dy, w)  (F.conv2d backward w.r.t. input) */
 int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
                         const void* w_packed_dgrad, void* dx, int64_t xsw, int H, int W, int Cin, int groups, int kh, int kw,

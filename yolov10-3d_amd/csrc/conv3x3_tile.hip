@@ -23,6 +23,9 @@ struct C3P {
   const void* w;   // packed [G][Cn][9][Cg] (forward) or [G][Cn][9][Cg] of the dgrad packing; row pitch Ktot
   void* y;
   float* part;     // optional BN partials [B*nty*ntx][G*Cn][2]
+  const float* scale;  // optional per-channel affine (+SiLU) epilogue (eval-mode BatchNorm)
+  const float* shift;
+  int act;
   long xsb, xsh, xsw, ysw;
   int B, H, W;
   int Cg, Cn, G;
@@ -203,13 +206,20 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     const int co = c0 + wc * 64 + ct * 16 + lc;
+    float sv[4] = {1.f, 1.f, 1.f, 1.f}, hv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (co + j < p.Cn) { sv[j] = p.scale[g * p.Cn + co + j]; hv[j] = p.shift[g * p.Cn + co + j]; }
+    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int yy = y0 + 4 * wp + pt;
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = xok ? TT<T>::rnd(acc[ct][pt][j]) : 0.f;
+        float u = acc[ct][pt][j];
+        if (p.scale) { u = u * sv[j] + hv[j]; if (p.act) u = silu_f(u); }
+        v[j] = xok ? TT<T>::rnd(u) : 0.f;
         ssum[ct][j] += v[j];
         ssq[ct][j] += v[j] * v[j];
       }
@@ -289,9 +299,10 @@ int y3d_tile_height(int dtype, int H, int W, int Cg, int kh, int kw, int stride,
 }
 
 int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G,
-                            const void* w, int Ktot, void* y, long ysw, float* part, int flip, void* stream) {
+                            const void* w, int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act,
+                            void* stream) {
   C3P p;
-  p.x = x; p.w = w; p.y = y; p.part = part;
+  p.x = x; p.w = w; p.y = y; p.part = part; p.scale = scale; p.shift = shift; p.act = act;
   p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = ysw;
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
   p.ntx = cdiv(W, 16); p.nty = H / th; p.ntc = cdiv(Cn, 128); p.flip = flip;

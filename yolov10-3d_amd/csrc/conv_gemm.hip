@@ -21,6 +21,9 @@ struct ConvP {
   const void* x;   // gathered tensor (fwd: input, dgrad: dy)
   const void* w;   // packed weights [G][Cn][Kpad]
   const float* bias;
+  const float* scale;  // optional per-channel affine (+SiLU) epilogue: eval-mode BatchNorm folded into the conv launch
+  const float* shift;
+  int act;
   void* y;         // output tensor, pixel-dense
   float* part;     // optional BN partials [gridDim.x][G*Cn][2]
   long xsb, xsh, xsw;
@@ -204,9 +207,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
   for (int a = 0; a < TC; ++a) {
     const int co = c0 + wc * (BC / WC) + a * 16 + lc;  // first of 4 consecutive channels
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    float sv[4] = {1.f, 1.f, 1.f, 1.f}, hv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (co + j < p.Cn) bv[j] = p.bias[g * p.Cn + co + j];
+    }
+    if (p.scale) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (co + j < p.Cn) { sv[j] = p.scale[g * p.Cn + co + j]; hv[j] = p.shift[g * p.Cn + co + j]; }
     }
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
@@ -214,7 +222,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = TT<T>::rnd(acc[a][b][j] + bv[j]);
+        float u = acc[a][b][j] + bv[j];
+        if (p.scale) { u = u * sv[j] + hv[j]; if (p.act) u = silu_f(u); }
+        v[j] = TT<T>::rnd(u);
         ssum[a][j] += v[j];
         ssq[a][j] += v[j] * v[j];
       }
@@ -517,7 +527,8 @@ int launch_conv(ConvP p, hipStream_t st) {
 // conv3x3_tile.hip
 int y3d_tile_height(int dtype, int H, int W, int Cg, int kh, int kw, int stride, int pad);
 int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G,
-                            const void* w, int Ktot, void* y, long ysw, float* part, int flip, void* stream);
+                            const void* w, int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act,
+                            void* stream);
 
 // conv3x3_wgrad_tile.hip
 int y3d_wgrad_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad);
@@ -591,9 +602,9 @@ static int check_align(const char* what, const void* ptr, long s0, long s1, long
   return Y3D_OK;
 }
 
-int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
-                   const void* w_packed, const float* bias, void* y, int64_t ysw, int Ho, int Wo, int Cout, int groups,
-                   int kh, int kw, int stride, int pad, float* stat_partials, void* stream) {
+static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                           const void* w_packed, const float* bias, const float* scale, const float* shift, int act, void* y, int64_t ysw,
+                           int Ho, int Wo, int Cout, int groups, int kh, int kw, int stride, int pad, float* stat_partials, void* stream) {
   int ce = dtype == Y3D_BF16 ? 8 : 4;
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "conv2d_fwd: bad dtype %d", dtype);
   Y3D_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && groups > 0, "conv2d_fwd: empty shape");
@@ -607,7 +618,7 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
   Y3D_CHECK(((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 7) == 0, "conv2d_fwd: w/y alignment");
   Y3D_CHECK((long)B * Ho * Wo < (1L << 31), "conv2d_fwd: too many pixels");
   ConvP p;
-  p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.part = stat_partials;
+  p.x = x; p.w = w_packed; p.bias = bias; p.scale = scale; p.shift = shift; p.act = act; p.y = y; p.part = stat_partials;
   p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = ysw;
   p.B = B; p.Hg = H; p.Wg = W; p.Hq = Ho; p.Wq = Wo;
   p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
@@ -615,10 +626,25 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
   p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
   if (!bias && g_tile_kernels) {
     int th = y3d_tile_height(dtype, H, W, p.Cg, kh, kw, stride, pad);
-    if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, stream);
+    if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, scale, shift, act, stream);
   }
   if (dtype == Y3D_BF16) return launch_conv<bf16_t, false>(p, (hipStream_t)stream);
   return launch_conv<float, false>(p, (hipStream_t)stream);
+}
+
+int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                   const void* w_packed, const float* bias, void* y, int64_t ysw, int Ho, int Wo, int Cout, int groups,
+                   int kh, int kw, int stride, int pad, float* stat_partials, void* stream) {
+  return conv2d_fwd_impl(dtype, x, xsb, xsh, xsw, B, H, W, Cin, w_packed, bias, nullptr, nullptr, 0, y, ysw, Ho, Wo, Cout, groups, kh, kw,
+                         stride, pad, stat_partials, stream);
+}
+
+int y3d_conv2d_fwd_affine(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                          const void* w_packed, const float* scale, const float* shift, int act, void* y, int64_t ysw, int Ho, int Wo,
+                          int Cout, int groups, int kh, int kw, int stride, int pad, void* stream) {
+  Y3D_CHECK(scale && shift, "conv2d_fwd_affine: scale/shift required");
+  return conv2d_fwd_impl(dtype, x, xsb, xsh, xsw, B, H, W, Cin, w_packed, nullptr, scale, shift, act, y, ysw, Ho, Wo, Cout, groups, kh, kw,
+                         stride, pad, nullptr, stream);
 }
 
 int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
@@ -633,7 +659,7 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   Y3D_CHECK(kh * kw <= 64, "conv2d_bwd_data: at most 64 filter taps");
   if (check_align("conv2d_bwd_data dy", dy, dsb, dsh, dsw, ce)) return Y3D_ERR_INVALID;
   ConvP p;
-  p.x = dy; p.w = w_packed_dgrad; p.bias = nullptr; p.y = dx; p.part = nullptr;
+  p.x = dy; p.w = w_packed_dgrad; p.bias = nullptr; p.scale = nullptr; p.shift = nullptr; p.act = 0; p.y = dx; p.part = nullptr;
   p.xsb = dsb; p.xsh = dsh; p.xsw = dsw; p.ysw = xsw;
   p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hq = H; p.Wq = W;
   p.Cg = Cout / groups; p.Cn = Cin / groups; p.G = groups;
@@ -643,7 +669,7 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
     // a 3x3 s1 p1 data gradient is the same conv on dy with flipped taps (Ho == H, Wo == W)
     int th = y3d_tile_height(dtype, Ho, Wo, p.Cg, kh, kw, stride, pad);
     if (th && Ho == H && Wo == W)
-      return y3d_conv3x3_tile_launch(dtype, th, dy, dsb, dsh, dsw, B, H, W, p.Cg, p.Cn, groups, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, stream);
+      return y3d_conv3x3_tile_launch(dtype, th, dy, dsb, dsh, dsw, B, H, W, p.Cg, p.Cn, groups, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, nullptr, nullptr, 0, stream);
   }
   if (dtype == Y3D_BF16) return launch_conv<bf16_t, true>(p, (hipStream_t)stream);
   return launch_conv<float, true>(p, (hipStream_t)stream);

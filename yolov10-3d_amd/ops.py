@@ -169,6 +169,13 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         Cg_pad = Cin_k // g
         wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
         L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
+        if not training and not res_mode:
+            # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor
+            ss = _f32(2 * Cout, dev).view(2, Cout)
+            L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, ss[0].data_ptr(), ss[1].data_ptr(), st)
+            L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), int(act),
+                                y.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p, st)
+            return y, None, None
         _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
                lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
                                     k, k, s, p, part.data_ptr() if training else None, st))
@@ -274,11 +281,14 @@ class ConvBNActFn(torch.autograd.Function):
         if m.training:
             m._nbt_pending += 1
         ctx.cfg = cfg
-        ctx.save_for_backward(*saved)
+        if saved is not None:
+            ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
+        if ctx.cfg is None:
+            raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
         dx, dW, dg, db, dres = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], ctx.needs_input_grad[4])
         return dx, dW, dg, db, dres, None, None
 
@@ -342,7 +352,8 @@ class FusedConvBNActFn(torch.autograd.Function):
             for c in stack.convs:
                 c._nbt_pending += 1
         ctx.cfg, ctx.couts, ctx.dx_range = cfg, stack.couts, dx_range
-        ctx.save_for_backward(*saved)
+        if saved is not None:
+            ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
