@@ -432,16 +432,31 @@ class v10Detect3d(nn.Module):
             dr = torch.arange(ps, device=xi.device)
             patches = xp[bidx[:, None, None], :, (rows[:, None] + dr)[:, :, None], (cols[:, None] + dr)[:, None, :]]  # (BK, ps, ps, C)
             patches = patches.permute(0, 3, 1, 2)  # logical NCHW over NHWC memory
-            feats = []
-            for j in range(1, 8):
-                br = heads[j][i]
-                p0, p1 = br[0].conv.padding, br[1].conv.padding
-                br[0].conv.padding, br[1].conv.padding = (0, 0), (0, 0)  # patch semantics: both convs unpadded (head.py:706-708)
-                try:
-                    feats.append(br[1](br[0](patches)))
-                finally:
-                    br[0].conv.padding, br[1].conv.padding = p0, p1  # unlike the reference we do not leave the module mutated
-            reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
+            _, mids, s1, s2 = self._stacks(i)
+            if heads is self.o2o_heads and s2 is not None:
+                # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
+                # (channel rows mid..8*mid of the training-time stacks), both unpadded: patch semantics of head.py:706-708
+                mid, c0 = mids[0], heads[1][i][0]
+                lo, hi = mid, 8 * mid
+                w1, g1, b1, rm1, rv1 = s1.tensors()
+                z1 = ops.conv_bn_act_eval(patches, w1[lo:hi], g1[lo:hi], b1[lo:hi], rm1[lo:hi], rv1[lo:hi], self.kernel_size_1, 1, 0, 1,
+                                          c0.has_act, c0.eps, s1.__dict__.setdefault("_eval_cache", {}))
+                w2, g2, b2, rm2, rv2 = s2.tensors()
+                z2 = ops.conv_bn_act_eval(z1, w2[lo:hi], g2[lo:hi], b2[lo:hi], rm2[lo:hi], rv2[lo:hi], self.kernel_size_2, 1, 0, 7,
+                                          c0.has_act, c0.eps, s2.__dict__.setdefault("_eval_cache", {}))
+                reg = ops.HeadProjSlicesFn.apply(z2, [j * mid for j in range(7)], [mid] * 7, 7, *[heads[j][i][2].weight for j in range(1, 8)],
+                                                 *[heads[j][i][2].bias for j in range(1, 8)])[:, :, 0, 0]
+            else:
+                feats = []
+                for j in range(1, 8):
+                    br = heads[j][i]
+                    p0, p1 = br[0].conv.padding, br[1].conv.padding
+                    br[0].conv.padding, br[1].conv.padding = (0, 0), (0, 0)  # patch semantics: both convs unpadded (head.py:706-708)
+                    try:
+                        feats.append(br[1](br[0](patches)))
+                    finally:
+                        br[0].conv.padding, br[1].conv.padding = p0, p1  # unlike the reference we do not leave the module mutated
+                reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
             full = torch.zeros(B, H, W, self.no, dtype=cls.dtype, device=xi.device)
             full[..., : self.nc] = cls.permute(0, 2, 3, 1)
             full[bidx, rows, cols, self.nc:] = reg

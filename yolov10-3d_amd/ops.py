@@ -117,6 +117,13 @@ TIMER = None  # set by bench.py
 # ------------------------------------------------------------------------------------------------------
 # Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
 # ------------------------------------------------------------------------------------------------------
+def conv_bn_act_eval(x, w, gamma, beta, rm, rv, k, s, p, g, act, eps, cache=None):
+    """eval-mode act(bn(conv(x))) on explicit (possibly stacked / sliced) tensors; no autograd.  `cache`: a dict owned by the
+    caller that keeps the packed weights + folded BatchNorm scale/shift until a parameter changes"""
+    z, _, _ = _cba_forward(x, w, gamma, beta, rm, rv, k, s, p, g, act, None, 0, False, eps, 0.0, cache)
+    return z
+
+
 def _timed(key, launch):
     if TIMER is not None:
         TIMER.bracket(key, launch)
@@ -124,7 +131,7 @@ def _timed(key, launch):
         launch()
 
 
-def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum):
+def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None):
     """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs."""
     L = lib()
     _require_gpu(x)
@@ -167,15 +174,27 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         if training:
             part = _f32(nblk * Cout * 2, dev)
         Cg_pad = Cin_k // g
-        wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
-        L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
         if not training and not res_mode:
-            # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor
-            ss = _f32(2 * Cout, dev).view(2, Cout)
-            L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, ss[0].data_ptr(), ss[1].data_ptr(), st)
+            # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor; the packed
+            # weights and the scale/shift pair are cached until a parameter / buffer is modified in place or re-pointed
+            key = (w32.data_ptr(), w32._version, g32.data_ptr(), g32._version, b32._version, rm.data_ptr(), rm._version, rv._version,
+                   dtype, k, g, Cg_pad, Cout, float(eps))
+            hit = cache.get(key) if cache is not None else None
+            if hit is None:
+                wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
+                L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
+                ss = _f32(2 * Cout, dev).view(2, Cout)
+                L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, ss[0].data_ptr(), ss[1].data_ptr(), st)
+                hit = (wp, ss)
+                if cache is not None:  # owned by the module / stack, so it dies with the tensors it describes
+                    cache.clear()
+                    cache[key] = hit
+            wp, ss = hit
             L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), int(act),
                                 y.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p, st)
             return y, None, None
+        wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
+        L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
         _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
                lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
                                     k, k, s, p, part.data_ptr() if training else None, st))
@@ -277,7 +296,8 @@ class ConvBNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, res, res_mode, m):
         z, cfg, saved = _cba_forward(x, _w32(weight), gamma.detach().float(), beta.detach().float(), m.bn.running_mean, m.bn.running_var,
-                                     m.k, m.s, m.p, m.g, m.has_act, res, res_mode, m.training, m.eps, m.momentum)
+                                     m.k, m.s, m.p, m.g, m.has_act, res, res_mode, m.training, m.eps, m.momentum,
+                                     m.__dict__.setdefault("_eval_cache", {}))
         if m.training:
             m._nbt_pending += 1
         ctx.cfg = cfg
