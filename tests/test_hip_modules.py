@@ -468,3 +468,28 @@ def test_tile_kernels_agree_with_generic_kernels(case):
             L.set_tile_kernels(old)
     for a, b, what, tol in zip(outs[1], outs[0], ("y", "dx", "dW"), (2e-2, 2e-2, 2e-3)):
         check(a, b, tol, f"tile vs generic {what}")
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 20, 2), (1, 7, 11, 1), (1, 40, 40, 4)])
+def test_attention_mfma_vs_valu(shape):
+    """bf16 PSA attention: MFMA kernel (S^T = K Q^T, O^T = V^T P^T on the matrix cores) vs the fp32-VALU kernel on the same qkv"""
+    B, H, W, nh = shape
+    y3d.set_compute_dtype(torch.bfloat16)
+    L = y3d.lib()
+    torch.manual_seed(2)
+    kd, hd = 32, 64
+    qkv = y3d.ops.to_nhwc(torch.randn(B, nh * (2 * kd + hd), H, W, device=DEV), torch.bfloat16)
+    res = {}
+    for enable in (1, 0):
+        old = L.set_tile_kernels(enable)
+        try:
+            o, v = y3d.ops.AttentionFn.apply(qkv, nh, kd, hd, kd ** -0.5)
+            res[enable] = o.float().clone()
+        finally:
+            L.set_tile_kernels(old)
+    check(res[1], res[0], 2e-2, "attention MFMA vs VALU")
+    # and against plain fp32 math
+    q, k, vv = qkv.float().view(B, nh, 2 * kd + hd, H * W).split([kd, kd, hd], 2)
+    attn = ((q.transpose(-2, -1) @ k) * kd ** -0.5).softmax(-1)
+    ref = (vv @ attn.transpose(-2, -1)).view(B, nh * hd, H, W)
+    check(res[1], ref, 2e-2, "attention MFMA vs fp32 math")

@@ -7,8 +7,11 @@
 // QK^T variant is listed in DESIGN.md as the next step for this kernel.
 #include "common.h"
 
+extern "C" int y3d_get_tile_kernels(void);
+
 namespace {
 
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 constexpr int TK = 64;
 
 struct AttnP {
@@ -198,6 +201,112 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(AttnBP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MFMA forward (bf16, kd = 32, hd = 64): S^T = K Q^T and O^T = V^T P^T on the matrix cores.
+// One wave owns 16 queries.  S^T tiles come out of `mfma(A = K rows, B = Q rows)` with the query on the lane and four keys in
+// the registers - exactly the B-operand layout the second product needs (`An accumulator tile as the next MFMA's operand`), so
+// P never leaves the registers.  The reduction index of O^T = V^T P^T is the key; its MFMA-k <-> key assignment is permuted
+// (k = 8g+j <-> key 32*ks + 16*(j>>2) + 4g + (j&3)) to match the S^T accumulator layout, and V^T fragments are fetched from a
+// swizzled LDS image of V with the transposed read.  Softmax is two-pass (row max first: QK^T is one MFMA per 16 x 16 tile, so
+// recomputing it is cheaper than rescaling O), fp32 throughout.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int KC = 512;  // keys per LDS chunk of V (64 KB)
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
+  typedef bf16_t T;
+  constexpr int KD = 32, HD = 64;
+  extern __shared__ __attribute__((aligned(16))) char sV[];  // [KC][128 B], 16-byte chunks XOR-swizzled by ((row>>1)&3)<<1
+  const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int hoff = h * (2 * KD + HD);
+  const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
+  // Q fragment (B operand): query q0 + li, elements 8*grp .. 8*grp+7
+  bf16x8_t fq = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  if (q0 + li < p.N) fq = __builtin_bit_cast(bf16x8_t, *(const uint4*)(base + (long)(q0 + li) * p.qsw + 8 * grp));
+  const int ntile = (p.N + 15) / 16;
+  auto score_tile = [&](int t) -> f32x4_t {  // S^T tile: reg r <-> key 16t + 4*grp + r, column <-> query q0 + li
+    bf16x8_t fk = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    int key = 16 * t + li;
+    if (key < p.N) fk = __builtin_bit_cast(bf16x8_t, *(const uint4*)(base + (long)key * p.qsw + KD + 8 * grp));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  };
+  // pass 1: row maxima
+  float m = -INFINITY;
+  for (int t = 0; t < ntile; ++t) {
+    f32x4_t s = score_tile(t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * t + 4 * grp + r < p.N) m = fmaxf(m, s[r]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  const float ms = m * p.scale;
+  // pass 2
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int c0 = 0; c0 < p.N; c0 += KC) {
+    const int nk = min(KC, p.N - c0);
+    const int nk32 = (nk + 31) & ~31;
+    __syncthreads();
+    for (int id = tid; id < nk32 * 8; id += 256) {
+      int P = id >> 3, s8 = id & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (P < nk) v = *(const uint4*)(base + (long)(c0 + P) * p.qsw + 2 * KD + ((s8 ^ (((P >> 1) & 3) << 1)) * 8));
+      *(uint4*)(sV + id * 16) = v;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk32 / 32; ++ks) {
+      float pv[8];
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        int t = (c0 >> 4) + 2 * ks + hi;
+        f32x4_t s = score_tile(t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = (16 * t + 4 * grp + r < p.N) ? __expf(s[r] * p.scale - ms) : 0.f;
+          pv[hi * 4 + r] = e;
+          l += e;
+        }
+      }
+      bf16x8_t fp;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fp[j] = (__bf16)pv[j];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int cch = (dt * 16 >> 3) + (pp4 >> 1);
+        s16x4_t v[2];
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+          const int P = ks * 32 + 16 * hi + 4 * grp + qq;
+          const char* a = sV + P * 128 + ((cch ^ (((P >> 1) & 3) << 1)) << 4) + (pp4 & 1) * 8;
+          v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
+        }
+        bf16x8_t fv = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (q0 + li < p.N) {
+    const float inv = 1.f / l;
+    T* dst = (T*)p.out + ((long)b * p.N + q0 + li) * p.osw + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 u;
+      u.x = (unsigned)f2bf(o[dt][0] * inv) | ((unsigned)f2bf(o[dt][1] * inv) << 16);
+      u.y = (unsigned)f2bf(o[dt][2] * inv) | ((unsigned)f2bf(o[dt][3] * inv) << 16);
+      *(uint2*)(dst + dt * 16 + 4 * grp) = u;
+    }
+    if (grp == 0) p.lse[((long)b * p.nh + h) * p.N + q0 + li] = ms + __logf(l);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -209,6 +318,16 @@ int y3d_attn_fwd(int dtype, const void* qkv, int64_t qsw, void* out, int64_t osw
   AttnP p{qkv, (long)qsw, out, (long)osw, lse, B, N, nh, kd, hd, scale};
   dim3 grid(cdiv(N, 128), B * nh), block(128);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16 && kd == 32 && y3d_get_tile_kernels() && qsw % 8 == 0 && osw % 4 == 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KC * 128);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), KC * 128, st, p);
+    Y3D_LAUNCH_CHECK();
+    return Y3D_OK;
+  }
   if (dtype == Y3D_BF16) {
     if (kd == 32) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 32, 64>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 36, 72>), grid, block, 0, st, p);

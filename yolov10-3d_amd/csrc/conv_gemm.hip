@@ -541,6 +541,8 @@ extern "C" int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cou
 
 extern "C" {
 
+int y3d_get_tile_kernels(void) { return g_tile_kernels; }
+
 int y3d_set_tile_kernels(int enable) {
   int old = g_tile_kernels;
   g_tile_kernels = enable ? 1 : 0;
