@@ -196,6 +196,26 @@ int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, v
                const int* target_gt_idx, const float* target_scores, const float* scal, float w_loss2d, float w_cls, float w_depth,
                float w_offset3d, float w_size3d, float w_heading, float grad_scale, float* partials, float* items, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Eval-side selection (post.hip): v10Detect3d.select_candidates / extract_patches / scatter / decode (head.py:656-716,
+ * 755-797) and v10_3Dpostprocess / v10postprocess (utils/ops.py:852-880).  Ties go to the lowest index.
+ * ---------------------------------------------------------------------------------------------- */
+/* out_idx (B, K) int32: flat cell index (row*W + col) of the K largest max-class logits of each image; cls: (B, HW, >= nc), pixel stride psw */
+int y3d_topk_cells(int dtype, const void* cls, int64_t psw, int B, int HW, int nc, int K, int* out_idx, void* stream);
+/* out (B*K, ps, ps, C) NHWC: zero-padded ps x ps input patches centred on the selected cells */
+int y3d_patch_gather(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, const int* idx, void* out, int B, int H, int W,
+                     int C, int K, int ps, void* stream);
+/* map (B, HW, no): dense cls channels + the (no - nc) regression channels of the candidate on each selected cell, zeros elsewhere */
+int y3d_head3d_scatter(int dtype, const void* cls, int64_t csw, const void* reg, int64_t rsw, const int* idx, void* map, int B, int HW,
+                       int nc, int no, int K, void* stream);
+/* y (B, nc+35, A) fp32 from the per-level (B, H, W, nc+35) maps: xyxy px boxes, centre-3d px, the rest copied */
+int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, const int* W, const float* strides, int B, int nc,
+                      float* y, void* stream);
+/* y (B, C, A) fp32; scores are the first nc rows (3D, boxes_first = 0) or the last nc rows (2D, boxes_first = 1).
+ * reg (B, max_det, C-nc), scores (B, max_det), labels (B, max_det) int64 */
+int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
+                        int64_t* labels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -493,3 +493,17 @@ def test_attention_mfma_vs_valu(shape):
     attn = ((q.transpose(-2, -1) @ k) * kd ** -0.5).softmax(-1)
     ref = (vv @ attn.transpose(-2, -1)).view(B, nh * hd, H, W)
     check(res[1], ref, 2e-2, "attention MFMA vs fp32 math")
+
+
+def test_postprocess_hip_vs_reference_golden():
+    from yolov10_3d_amd.loss import v10_3Dpostprocess, v10postprocess
+    g = load_golden("post3d")
+    reg, sc, lab = v10_3Dpostprocess(g["preds"].to(DEV), 50, 3)
+    assert torch.equal(lab.cpu(), g["labels"].long())
+    check(reg, g["reg"], 1e-6, "post3d reg")
+    check(sc, g["scores"], 1e-6, "post3d scores")
+    g = load_golden("post2d")
+    bx, sc, lab = v10postprocess(g["preds"].to(DEV), 300, 80)
+    assert torch.equal(lab.cpu(), g["labels"].long())
+    check(bx, g["boxes"], 1e-6, "post2d boxes")
+    check(sc, g["scores"], 1e-6, "post2d scores")

@@ -91,15 +91,10 @@ def test_loss2d_cpu():
         close(a.grad, b, atol=1e-6)
 
 
-def test_postprocess_cpu():
+def test_postprocess_refuses_cpu_tensors():
     g = load_golden("post3d")
-    reg, sc, lab = PL.v10_3Dpostprocess(g["preds"], 50, 3)
-    assert torch.equal(lab, g["labels"].long())
-    close(reg, g["reg"])
-    g = load_golden("post2d")
-    bx, sc, lab = PL.v10postprocess(g["preds"], 300, 80)
-    assert torch.equal(lab, g["labels"].long())
-    close(bx, g["boxes"])
+    with pytest.raises(y3d.Y3DError):
+        PL.v10_3Dpostprocess(g["preds"], 50, 3)
 
 
 def test_no_positive_zero_ties_in_fixtures():

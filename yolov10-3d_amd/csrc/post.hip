@@ -1,0 +1,252 @@
+// Eval-side selection kernels of the NMS-free YOLOv10-3D head (HBM / latency bound, integer outputs):
+//   * top-K cells of the max-class logit per image and level      (v10Detect3d.select_candidates, head.py:686-692)
+//   * (k1+k2-1)^2 zero-padded input patches around those cells    (extract_patches, head.py:663-684)
+//   * scatter of the per-candidate regression outputs + dense cls into the (B, H, W, no) map (head.py:709-713)
+//   * decode to (B, no, A): xyxy px boxes, centre-3d px            (decode / inference, head.py:755-797)
+//   * v10_3Dpostprocess: top-k over anchors, then over k x nc      (utils/ops.py:867-880)
+// Ties are broken towards the lowest index (the reference's CUDA radix select leaves the order unspecified).
+#include "common.h"
+
+namespace {
+
+// block-wide arg-max of (value desc, index asc) over `n` LDS values, K times, excluding earlier winners by overwriting them
+__device__ void block_topk(float* vals, int n, int K, int* out_idx, float* out_val, float* sv, int* si) {
+  for (int j = 0; j < K; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int a = threadIdx.x; a < n; a += blockDim.x) {
+      float v = vals[a];
+      if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        float v2 = sv[threadIdx.x + s];
+        int i2 = si[threadIdx.x + s];
+        if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      int w = si[0];
+      out_idx[j] = w < n ? w : 0;
+      if (out_val) out_val[j] = sv[0];
+      if (w < n) vals[w] = -INFINITY;  // -inf entries can only be re-selected when fewer than K finite values exist
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void topk_cells_kernel(const T* __restrict__ cls, long psw, int HW, int nc, int K, int* __restrict__ out) {
+  extern __shared__ float sm[];  // [HW] + reduction scratch
+  float* vals = sm;
+  float* sv = sm + HW;
+  int* si = (int*)(sv + 256);
+  const int b = blockIdx.x;
+  for (int a = threadIdx.x; a < HW; a += 256) {
+    const T* p = cls + ((long)b * HW + a) * psw;
+    float m = TT<T>::ld(p);
+    for (int c = 1; c < nc; ++c) m = fmaxf(m, TT<T>::ld(p + c));
+    vals[a] = m;
+  }
+  __syncthreads();
+  block_topk(vals, HW, K, out + (long)b * K, nullptr, sv, si);
+}
+
+// patches[(b*K + j)][py][px][c] = x[b][row - pad + py][col - pad + px][c]  (zero outside the map)
+template <typename T>
+__global__ void patch_gather_kernel(const T* __restrict__ x, long xsb, long xsh, long xsw, const int* __restrict__ idx, T* __restrict__ out,
+                                    int B, int H, int W, int C, int K, int ps) {
+  constexpr int CE = TT<T>::CE;
+  const int cpr = C / CE, pad = ps / 2;
+  long total = (long)B * K * ps * ps * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % cpr) * CE;
+    long r = i / cpr;
+    int px = (int)(r % ps);
+    r /= ps;
+    int py = (int)(r % ps);
+    long bk = r / ps;
+    int b = (int)(bk / K);
+    int cell = idx[bk];
+    int hh = cell / W - pad + py, ww = cell % W - pad + px;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = *(const uint4*)(x + (long)b * xsb + (long)hh * xsh + (long)ww * xsw + c);
+    *(uint4*)(out + i * CE) = v;
+  }
+}
+
+// map[b][cell][0:nc] = cls, map[b][cell][nc:no] = reg of the candidate sitting on that cell, else 0
+template <typename T>
+__global__ void head_scatter_kernel(const T* __restrict__ cls, long csw, const T* __restrict__ reg, long rsw, const int* __restrict__ idx,
+                                    T* __restrict__ map, int B, int HW, int nc, int no, int K) {
+  long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / HW), cell = (int)(i - (long)b * HW);
+    T* m = map + i * no;
+    const T* cp = cls + i * csw;
+    for (int c = 0; c < nc; ++c) m[c] = cp[c];
+    int hit = -1;
+    for (int j = 0; j < K; ++j)
+      if (idx[(long)b * K + j] == cell) hit = j;  // indices are unique per image
+    if (hit >= 0) {
+      const T* rp = reg + ((long)b * K + hit) * rsw;
+      for (int c = nc; c < no; ++c) m[c] = rp[c - nc];
+    } else {
+      for (int c = nc; c < no; ++c) TT<T>::st(m + c, 0.f);
+    }
+  }
+}
+
+struct DecL {
+  const void* map[4];
+  int H[4], W[4], a0[4];
+  float stride[4];
+  int nl, A, nc, no;
+};
+
+// y[b][c][a] (fp32): cls | xyxy px | centre-3d px | s3d | hd | dep | dep_un    (head.py:755-764)
+template <typename T>
+__global__ void head_decode_kernel(DecL L, float* __restrict__ y, int B) {
+  long total = (long)B * L.A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / L.A), a = (int)(i - (long)b * L.A);
+    int l = 0;
+    for (int k = 1; k < 4; ++k) if (k < L.nl && a >= L.a0[k]) l = k;
+    int r = a - L.a0[l];
+    int hy = r / L.W[l], hx = r - hy * L.W[l];
+    float ax = hx + 0.5f, ay = hy + 0.5f, st = L.stride[l];
+    const T* p = (const T*)L.map[l] + (((long)b * L.H[l] + hy) * L.W[l] + hx) * L.no;
+    float* o = y + (long)b * L.no * L.A + a;
+    const int nc = L.nc;
+    for (int c = 0; c < nc; ++c) o[(long)c * L.A] = TT<T>::ld(p + c);
+    float o2x = TT<T>::ld(p + nc), o2y = TT<T>::ld(p + nc + 1), s2x = TT<T>::ld(p + nc + 2) * st, s2y = TT<T>::ld(p + nc + 3) * st;
+    float cx = (o2x + ax) * st, cy = (o2y + ay) * st;
+    o[(long)(nc + 0) * L.A] = cx - s2x / 2.f;
+    o[(long)(nc + 1) * L.A] = cy - s2y / 2.f;
+    o[(long)(nc + 2) * L.A] = cx + s2x / 2.f;
+    o[(long)(nc + 3) * L.A] = cy + s2y / 2.f;
+    o[(long)(nc + 4) * L.A] = (TT<T>::ld(p + nc + 4) + ax) * st;
+    o[(long)(nc + 5) * L.A] = (TT<T>::ld(p + nc + 5) + ay) * st;
+    for (int c = nc + 6; c < L.no; ++c) o[(long)c * L.A] = TT<T>::ld(p + c);
+  }
+}
+
+// preds y (B, C, A) fp32 with `nc` score rows first: reg (B,K,C-nc), scores (B,K), labels (B,K) int64
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first,
+                                                          float* __restrict__ reg, float* __restrict__ scores, long* __restrict__ labels) {
+  extern __shared__ float sm[];
+  float* vals = sm;             // [A]
+  float* sv = sm + A;           // [256]
+  int* si = (int*)(sv + 256);   // [256]
+  int* top = si + 256;          // [K]
+  float* sc2 = (float*)(top + K);  // [K*nc]
+  int* top2 = (int*)(sc2 + K * nc);  // [K]
+  float* val2 = (float*)(top2 + K);  // [K]
+  const int b = blockIdx.x;
+  const float* yb = y + (long)b * C * A;
+  const int s0 = boxes_first ? C - nc : 0;   // first score row
+  const int r0 = boxes_first ? 0 : nc;       // first regression row
+  const int nr = C - nc;
+  for (int a = threadIdx.x; a < A; a += 256) {
+    float m = yb[(long)s0 * A + a];
+    for (int c = 1; c < nc; ++c) m = fmaxf(m, yb[(long)(s0 + c) * A + a]);
+    vals[a] = m;
+  }
+  __syncthreads();
+  block_topk(vals, A, K, top, nullptr, sv, si);
+  for (int i = threadIdx.x; i < K * nc; i += 256) sc2[i] = yb[(long)(s0 + i % nc) * A + top[i / nc]];
+  __syncthreads();
+  block_topk(sc2, K * nc, K, top2, val2, sv, si);
+  for (int i = threadIdx.x; i < K; i += 256) {
+    scores[(long)b * K + i] = val2[i];
+    labels[(long)b * K + i] = top2[i] % nc;
+  }
+  for (int i = threadIdx.x; i < K * nr; i += 256) {
+    int j = i / nr, c = i - j * nr;
+    reg[((long)b * K + j) * nr + c] = yb[(long)(r0 + c) * A + top[top2[j] / nc]];
+  }
+}
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_topk_cells(int dtype, const void* cls, int64_t psw, int B, int HW, int nc, int K, int* out_idx, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "topk_cells: bad dtype");
+  Y3D_CHECK(K >= 1 && K <= HW, "topk_cells: need 1 <= K <= H*W (K=%d, H*W=%d)", K, HW);
+  size_t sm = (size_t)(HW + 512) * 4;
+  Y3D_CHECK(sm <= 160 * 1024, "topk_cells: map of %d cells does not fit LDS", HW);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16) {
+    (void)hipFuncSetAttribute((const void*)topk_cells_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(topk_cells_kernel<bf16_t>, dim3(B), dim3(256), sm, st, (const bf16_t*)cls, (long)psw, HW, nc, K, out_idx);
+  } else {
+    (void)hipFuncSetAttribute((const void*)topk_cells_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(topk_cells_kernel<float>, dim3(B), dim3(256), sm, st, (const float*)cls, (long)psw, HW, nc, K, out_idx);
+  }
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_patch_gather(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, const int* idx, void* out, int B, int H, int W,
+                     int C, int K, int ps, void* stream) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "patch_gather: bad dtype");
+  Y3D_CHECK(C % ce == 0 && ((uintptr_t)x & 15) == 0 && xsb % ce == 0 && xsh % ce == 0 && xsw % ce == 0, "patch_gather: alignment");
+  long total = (long)B * K * ps * ps * (C / ce);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)xsb, (long)xsh, (long)xsw, idx, (bf16_t*)out, B, H, W, C, K, ps);
+  else hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)xsb, (long)xsh, (long)xsw, idx, (float*)out, B, H, W, C, K, ps);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_head3d_scatter(int dtype, const void* cls, int64_t csw, const void* reg, int64_t rsw, const int* idx, void* map, int B, int HW,
+                       int nc, int no, int K, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "head3d_scatter: bad dtype");
+  long total = (long)B * HW;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(head_scatter_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cls, (long)csw, (const bf16_t*)reg, (long)rsw, idx, (bf16_t*)map, B, HW, nc, no, K);
+  else hipLaunchKernelGGL(head_scatter_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)cls, (long)csw, (const float*)reg, (long)rsw, idx, (float*)map, B, HW, nc, no, K);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, const int* W, const float* strides, int B, int nc,
+                      float* y, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "head3d_decode: bad dtype");
+  Y3D_CHECK(nl >= 1 && nl <= 4, "head3d_decode: 1..4 levels");
+  DecL L;
+  int a0 = 0;
+  for (int i = 0; i < 4; ++i) {
+    L.map[i] = i < nl ? maps[i] : nullptr;
+    L.H[i] = i < nl ? H[i] : 1; L.W[i] = i < nl ? W[i] : 1; L.a0[i] = a0; L.stride[i] = i < nl ? strides[i] : 1.f;
+    if (i < nl) a0 += H[i] * W[i];
+  }
+  L.nl = nl; L.A = a0; L.nc = nc; L.no = nc + 35;
+  long total = (long)B * a0;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(head_decode_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, L, y, B);
+  else hipLaunchKernelGGL(head_decode_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, L, y, B);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
+                        int64_t* labels, void* stream) {
+  Y3D_CHECK(max_det >= 1 && max_det <= A && nc >= 1 && nc < C, "v10_postprocess: bad sizes");
+  size_t sm = (size_t)(A + 512 + max_det * (nc + 3)) * 4;
+  Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: %d anchors do not fit LDS", A);
+  (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

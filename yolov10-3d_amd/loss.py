@@ -382,23 +382,29 @@ class v10DetectLoss:
         return lm + l1, torch.cat((im, i1))
 
 
+def _postprocess(preds, max_det, nc, boxes_first):
+    """preds (B, A, C) as the reference passes it (a permuted view of the head's (B, C, A) output): one HIP launch"""
+    if not preds.is_cuda:
+        raise Y3DError("v10 postprocess runs on the HIP kernel of post.hip: predictions must live on a HIP device")
+    B, A, C = preds.shape
+    y = preds.permute(0, 2, 1)
+    if not (y.is_contiguous() and y.dtype == torch.float32):
+        y = y.float().contiguous()
+    nr = C - nc
+    reg = torch.empty(B, max_det, nr, dtype=torch.float32, device=preds.device)
+    scores = torch.empty(B, max_det, dtype=torch.float32, device=preds.device)
+    labels = torch.empty(B, max_det, dtype=torch.int64, device=preds.device)
+    lib().v10_postprocess(y.data_ptr(), B, C, A, nc, max_det, int(boxes_first), reg.data_ptr(), scores.data_ptr(), labels.data_ptr(), ops.stream())
+    return reg, scores, labels
+
+
 def v10_3Dpostprocess(preds, max_det, nc=3):
-    """utils/ops.py:867-880"""
+    """utils/ops.py:867-880: top-k over anchors of the max-class score, then over the k*nc scores -> (reg, scores, labels)"""
     assert preds.shape[-1] == nc + 35
-    scores, reg = preds.split([nc, preds.shape[-1] - nc], -1)
-    _, idx = torch.topk(scores.amax(-1), max_det, dim=-1)
-    reg = reg.gather(1, idx.unsqueeze(-1).expand(-1, -1, reg.shape[-1]))
-    scores = scores.gather(1, idx.unsqueeze(-1).expand(-1, -1, nc))
-    s2, idx2 = torch.topk(scores.flatten(1), max_det, dim=-1)
-    return reg.gather(1, (idx2 // nc).unsqueeze(-1).expand(-1, -1, reg.shape[-1])), s2, idx2 % nc
+    return _postprocess(preds, max_det, nc, False)
 
 
 def v10postprocess(preds, max_det, nc=80):
     """utils/ops.py:852-865"""
     assert 4 + nc == preds.shape[-1]
-    boxes, scores = preds.split([4, nc], -1)
-    _, idx = torch.topk(scores.amax(-1), max_det, dim=-1)
-    boxes = boxes.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4))
-    scores = scores.gather(1, idx.unsqueeze(-1).expand(-1, -1, nc))
-    s2, idx2 = torch.topk(scores.flatten(1), max_det, dim=-1)
-    return boxes.gather(1, (idx2 // nc).unsqueeze(-1).expand(-1, -1, 4)), s2, idx2 % nc
+    return _postprocess(preds, max_det, nc, True)

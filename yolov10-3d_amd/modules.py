@@ -411,27 +411,30 @@ class v10Detect3d(nn.Module):
 
     # ---- sparse (eval) path: head.py:656-716 -----------------------------------------------------------------
     def select_candidates(self, scores):
-        B, _, H, W = scores.shape
-        m = scores.float().amax(1).reshape(B, -1)
-        idx = torch.topk(m, self.max_det, dim=1, largest=True)[1]
-        return idx // W, idx % W
+        """(B, K) int32 flat cell indices of the top-`max_det` max-class logits (head.py:686-692), HIP kernel"""
+        B, nc, H, W = scores.shape
+        if not ops.px_dense(scores):
+            scores = ops._dense_any(scores, scores.dtype)
+        idx = torch.empty(B, self.max_det, dtype=torch.int32, device=scores.device)
+        ops.lib().topk_cells(ops.code(scores.dtype), scores.data_ptr(), scores.stride(3), B, H * W, nc, self.max_det, idx.data_ptr(), ops.stream())
+        return idx
 
     def inference_forward_feat(self, x, heads):
-        ps, pad = self.patch_size, self.patch_size // 2
-        outs_ch = list(self.output_channels.values())
+        ps = self.patch_size
+        L = ops.lib()
         ys = []
         for i in range(self.nl):
-            xi = x[i]
+            xi = ops.to_nhwc(x[i], ops.compute_dtype())
             B, C, H, W = xi.shape
+            if H * W < self.max_det:
+                raise ValueError(f"level {i} has {H * W} cells < max_det={self.max_det} (reference head.py:690 needs H*W >= max_det)")
+            dt, st = ops.code(xi.dtype), ops.stream()
             cls = _proj([heads[0][i][2]], [heads[0][i][1](heads[0][i][0](xi))])
-            rows, cols = self.select_candidates(cls)  # (B, K)
-            K = rows.shape[1]
-            bidx = torch.arange(B, device=xi.device).repeat_interleave(K)
-            rows, cols = rows.reshape(-1), cols.reshape(-1)
-            xp = torch.nn.functional.pad(xi, (pad, pad, pad, pad))
-            dr = torch.arange(ps, device=xi.device)
-            patches = xp[bidx[:, None, None], :, (rows[:, None] + dr)[:, :, None], (cols[:, None] + dr)[:, None, :]]  # (BK, ps, ps, C)
-            patches = patches.permute(0, 3, 1, 2)  # logical NCHW over NHWC memory
+            idx = self.select_candidates(cls)  # (B, K) int32
+            K = idx.shape[1]
+            patches = ops.nhwc_empty(B * K, C, ps, ps, xi.dtype, xi.device)
+            sb, sh, sw = ops.s3(xi)
+            L.patch_gather(dt, xi.data_ptr(), sb, sh, sw, idx.data_ptr(), patches.data_ptr(), B, H, W, C, K, ps, st)
             _, mids, s1, s2 = self._stacks(i)
             if heads is self.o2o_heads and s2 is not None:
                 # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
@@ -457,24 +460,25 @@ class v10Detect3d(nn.Module):
                     finally:
                         br[0].conv.padding, br[1].conv.padding = p0, p1  # unlike the reference we do not leave the module mutated
                 reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
-            full = torch.zeros(B, H, W, self.no, dtype=cls.dtype, device=xi.device)
-            full[..., : self.nc] = cls.permute(0, 2, 3, 1)
-            full[bidx, rows, cols, self.nc:] = reg
-            ys.append(full.permute(0, 3, 1, 2))
+            reg = reg.contiguous()
+            full = ops.nhwc_empty(B, self.no, H, W, cls.dtype, xi.device)
+            L.head3d_scatter(dt, cls.data_ptr(), cls.stride(3), reg.data_ptr(), reg.stride(0), idx.data_ptr(), full.data_ptr(), B, H * W, self.nc,
+                             self.no, K, st)
+            ys.append(full)
         return ys
 
     def decode(self, ys):
-        """head.py:755-797: (B, no, A) fp32 with xyxy px boxes and centre-3d px."""
+        """head.py:755-797: (B, no, A) fp32 with xyxy px boxes and centre-3d px (HIP kernel over the per-level NHWC maps)."""
+        import ctypes
         B = ys[0].shape[0]
-        cat_ = torch.cat([y.permute(0, 2, 3, 1).reshape(B, -1, self.no) for y in ys], 1).float().permute(0, 2, 1)
-        anc, st = make_anchors([y.shape[2:] for y in ys], self.stride.tolist(), ys[0].device)
-        anc, st = anc.t(), st.t()
-        cls, o2d, s2d, o3d, s3d, hd, dep, dep_un = cat_.split((self.nc, 2, 2, 2, 3, 24, 1, 1), 1)
-        s2 = s2d * st
-        c2 = (o2d + anc) * st
-        bbox = torch.cat((c2 - s2 / 2, c2 + s2 / 2), 1)
-        c3 = (o3d + anc) * st
-        return torch.cat((cls, bbox, c3, s3d, hd, dep, dep_un), 1)
+        nl = len(ys)
+        ys = [y if (y.dtype == ys[0].dtype and ops.px_dense(y) and y.stride(3) == self.no) else ops._dense_any(y, ys[0].dtype) for y in ys]
+        A = sum(y.shape[2] * y.shape[3] for y in ys)
+        out = torch.empty(B, self.no, A, dtype=torch.float32, device=ys[0].device)
+        ops.lib().head3d_decode(ops.code(ys[0].dtype), nl, (ctypes.c_void_p * nl)(*[y.data_ptr() for y in ys]),
+                                (ctypes.c_int * nl)(*[y.shape[2] for y in ys]), (ctypes.c_int * nl)(*[y.shape[3] for y in ys]),
+                                (ctypes.c_float * nl)(*[float(s) for s in self.stride.tolist()[:nl]]), B, self.nc, out.data_ptr(), ops.stream())
+        return out
 
     def forward(self, x):
         x = list(x[: self.nl])
