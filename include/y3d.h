@@ -196,6 +196,17 @@ int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, v
                const int* target_gt_idx, const float* target_scores, const float* scal, float w_loss2d, float w_cls, float w_depth,
                float w_offset3d, float w_size3d, float w_heading, float grad_scale, float* partials, float* items, void* stream);
 
+/* 2D counterparts (tal_loss2d.hip): TaskAlignedAssigner utils/tal.py:45-94 and v8DetectionLoss utils/loss.py:206-257 (+BboxLoss :82-113,
+ * DFL block.py:59-62).  maps[l]: (B, H, W, 64 + nc) with channel order [4 x 16 DFL bins | nc class logits]; gt: (B, n, 5) = cls | box xyxy px.
+ * scratch as y3d_tal3d_scratch_floats.  items[3] = (box, cls, dfl) incl. gains; partials: 3 * ceil(B*A/256) floats */
+int y3d_tal2d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
+                     int B, int nc, const float* gt, int n, int topk, float alpha, float beta, float* scratch, uint8_t* fg_mask,
+                     int* target_gt_idx, float* target_scores, float* scal, void* stream);
+int y3d_loss2d(int dtype, int nl, const void* const* maps, const int64_t* psw, void* const* grads, const int64_t* gsw, const int* H,
+               const int* W, const float* strides, int B, int nc, const float* gt, int n, const uint8_t* fg_mask,
+               const int* target_gt_idx, const float* target_scores, const float* scal, float w_box, float w_cls, float w_dfl,
+               float grad_scale, float* partials, float* items, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Eval-side selection (post.hip): v10Detect3d.select_candidates / extract_patches / scatter / decode (head.py:656-716,
  * 755-797) and v10_3Dpostprocess / v10postprocess (utils/ops.py:852-880).  Ties go to the lowest index.

@@ -507,3 +507,38 @@ def test_postprocess_hip_vs_reference_golden():
     assert torch.equal(lab.cpu(), g["labels"].long())
     check(bx, g["boxes"], 1e-6, "post2d boxes")
     check(sc, g["scores"], 1e-6, "post2d scores")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss2d_hip_vs_reference_golden(dtype):
+    """fused HIP 2D assigner + BCE/CIoU/DFL loss + gradient (tal_loss2d.hip) on the reference's v10DetectLoss fixture"""
+    from types import SimpleNamespace
+    from yolov10_3d_amd import loss as PL
+    y3d.set_compute_dtype(dtype)
+    g = load_golden("loss2d")
+    strides = [float(s) for s in g["strides"]]
+    head = SimpleNamespace(stride=g["strides"], nc=80, no=144, reg_max=16)
+    crit = PL.v10DetectLoss(SimpleNamespace(model=[head], args=SimpleNamespace(**y3d.tasks.DEFAULT_HYP)))
+    src_m, src_o = g["o2m"], g["o2o"]
+    if dtype == torch.bfloat16:
+        src_m = [t.bfloat16().float() for t in src_m]
+        src_o = [t.bfloat16().float() for t in src_o]
+    o2m = [y3d.ops._dense_any(t.to(DEV), dtype).requires_grad_(True) for t in src_m]
+    o2o = [y3d.ops._dense_any(t.to(DEV), dtype).requires_grad_(True) for t in src_o]
+    batch = {k: v.to(DEV) for k, v in g["batch"].items()}
+    loss, items = crit({"one2many": o2m, "one2one": o2o}, batch)
+    loss.backward()
+    om = [t.clone().requires_grad_(True) for t in src_m]
+    oo = [t.clone().requires_grad_(True) for t in src_o]
+    lo, io, aux = RS.loss2d({"one2many": om, "one2one": oo}, g["batch"], strides, 80)
+    lo.backward()
+    for crit1, key in ((crit.one2many, "one2many"), (crit.one2one, "one2one")):
+        fg, gi, ts = crit1.last_assignment
+        assert torch.equal(fg.cpu(), aux[key]["fg_mask"]), f"{key}: fg_mask differs"
+        assert torch.equal(gi.cpu(), aux[key]["target_gt_idx"]), f"{key}: target_gt_idx differs"
+    check(items, io, 1e-3, "loss items vs oracle")
+    if dtype == torch.float32:
+        check(items, g["items"], 1e-3, "loss items vs reference fixture")
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
+    for a, b in zip(o2m + o2o, om + oo):
+        check(a.grad, b.grad, tol, "d loss / d map")

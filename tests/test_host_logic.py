@@ -77,20 +77,6 @@ def test_loss3d_refuses_cpu_tensors():
         crit({"one2many": g["o2m"], "one2one": g["o2o"]}, g["batch"])
 
 
-def test_loss2d_cpu():
-    from types import SimpleNamespace
-    g = load_golden("loss2d")
-    head = SimpleNamespace(stride=g["strides"], nc=80, no=144, reg_max=16)
-    crit = PL.v10DetectLoss(_FakeModel(head, SimpleNamespace(**y3d.tasks.DEFAULT_HYP)))
-    o2m = [t.clone().requires_grad_(True) for t in g["o2m"]]
-    o2o = [t.clone().requires_grad_(True) for t in g["o2o"]]
-    loss, items = crit({"one2many": o2m, "one2one": o2o}, g["batch"])
-    close(items, g["items"], rtol=1e-5)
-    loss.backward()
-    for a, b in zip(o2m + o2o, g["g_o2m"] + g["g_o2o"]):
-        close(a.grad, b, atol=1e-6)
-
-
 def test_postprocess_refuses_cpu_tensors():
     g = load_golden("post3d")
     with pytest.raises(y3d.Y3DError):
@@ -106,3 +92,10 @@ def test_no_positive_zero_ties_in_fixtures():
         targets, fg, gi = RS.tal3d(g["pd_scores"], g["pd_bboxes"], g["pd_3d"], g["anc"] * g["stride"], gts, g["mask_gt"], g["stride"],
                                    g["calib"], g["mean_sizes"], topk, 3)
         assert (targets[1].sum(-1)[fg] > 0).all()
+
+
+def test_fold_conv_bn_matches_reference_fixture():
+    g = load_golden("fold_bn")
+    w, b = y3d.tasks.fuse_conv_and_bn(g["w"], g["gamma"], g["beta"], g["mean"], g["var"])
+    close(w, g["w_folded"])
+    close(b, g["b_folded"])

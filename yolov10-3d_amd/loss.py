@@ -318,55 +318,95 @@ class DetectLoss3d:
         return torch.zeros(1), i1
 
 
+class Loss2dFn(torch.autograd.Function):
+    """2D head set: assignment + (box, cls, dfl) + gradient wrt the head maps on the fused HIP kernels of tal_loss2d.hip.
+    apply(cfg, gt(B,n,5), *maps) -> (sum_of_items, items[3], fg_mask, target_gt_idx, target_scores)"""
+
+    @staticmethod
+    def forward(ctx, cfg, gt, *maps):
+        L = lib()
+        strides, nc, topk, alpha, beta, w = cfg
+        dtype = maps[0].dtype
+        dt = ops.code(dtype)
+        st = ops.stream()
+        dev = maps[0].device
+        nl = len(maps)
+        for m in maps:
+            if not (m.is_cuda and ops.px_dense(m)):
+                raise Y3DError("Loss2dFn: head maps must be pixel-dense NHWC tensors on a HIP device")
+        B, no = maps[0].shape[:2]
+        Hs = [m.shape[2] for m in maps]
+        Ws = [m.shape[3] for m in maps]
+        A = sum(h * w_ for h, w_ in zip(Hs, Ws))
+        n = gt.shape[1]
+        gt = gt.float().contiguous()
+        grads = [ops.nhwc_empty(B, no, h, w_, dtype, dev) for h, w_ in zip(Hs, Ws)]
+        PV = ctypes.c_void_p * nl
+        c_maps, c_grads = PV(*[m.data_ptr() for m in maps]), PV(*[g.data_ptr() for g in grads])
+        c_psw = (ctypes.c_int64 * nl)(*[m.stride(3) for m in maps])
+        c_gsw = (ctypes.c_int64 * nl)(*[no] * nl)
+        c_H, c_W = (ctypes.c_int * nl)(*Hs), (ctypes.c_int * nl)(*Ws)
+        c_st = (ctypes.c_float * nl)(*strides)
+        nsc = L.tal3d_scratch_floats(B, n, A, topk)
+        if nsc < 0:
+            raise Y3DError("Loss2dFn: assignment scratch exceeds 2^31 floats")
+        scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
+        fg = torch.empty(B, A, dtype=torch.uint8, device=dev)
+        gi = torch.empty(B, A, dtype=torch.int32, device=dev)
+        ts = torch.empty(B, A, nc, dtype=torch.float32, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        L.tal2d_assign(dt, nl, c_maps, c_psw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, topk, alpha, beta, scratch.data_ptr(), fg.data_ptr(),
+                       gi.data_ptr(), ts.data_ptr(), scal.data_ptr(), st)
+        nblk = (B * A + 255) // 256
+        part = torch.empty(nblk * 3, dtype=torch.float32, device=dev)
+        items = torch.empty(3, dtype=torch.float32, device=dev)
+        L.loss2d(dt, nl, c_maps, c_psw, c_grads, c_gsw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, fg.data_ptr(), gi.data_ptr(), ts.data_ptr(),
+                 scal.data_ptr(), w[0], w[1], w[2], 1.0, part.data_ptr(), items.data_ptr(), st)
+        ctx.save_for_backward(*grads)
+        total = items.sum()
+        ctx.mark_non_differentiable(items, fg, gi, ts)
+        return total, items, fg, gi, ts
+
+    @staticmethod
+    def backward(ctx, d_total, *unused):
+        return (None, None, *[g * d_total.to(g.dtype) for g in ctx.saved_tensors])
+
+
 class v8DetectionLoss:
-    """utils/loss.py:157-257 (+BboxLoss :73-113)"""
+    """utils/loss.py:157-257 (+BboxLoss :73-113) on the HIP kernels of tal_loss2d.hip"""
 
     def __init__(self, model, tal_topk=10):
         m = model.model[-1]
         self.hyp = model.args
         self.stride = [float(s) for s in m.stride]
         self.nc, self.no, self.reg_max = m.nc, m.no, m.reg_max
-        self.assigner = TaskAlignedAssigner(topk=tal_topk, num_classes=self.nc, alpha=0.5, beta=6.0)
+        if self.reg_max != 16:
+            raise NotImplementedError("the DFL kernels are built for reg_max = 16")
+        self.topk = tal_topk
+        self.assigner = TaskAlignedAssigner(topk=tal_topk, num_classes=self.nc, alpha=0.5, beta=6.0)  # torch-op formulation (tests)
 
     def __call__(self, preds, batch):
         feats = preds[1] if isinstance(preds, tuple) else preds
         dev = feats[0].device
+        if not feats[0].is_cuda:
+            raise Y3DError("the 2D loss runs on the HIP kernels of tal_loss2d.hip: head maps must live on a HIP device (no CPU fallback)")
         B = feats[0].shape[0]
-        cat = _flatten_maps(feats)
-        dist, sc = cat.split((self.reg_max * 4, self.nc), -1)
         H, W = feats[0].shape[2:]
         imgsz = torch.tensor([H, W], dtype=torch.float32, device=dev) * self.stride[0]
-        anc, st = make_anchors([f.shape[2:] for f in feats], self.stride, dev)
         rows = torch.cat((batch["batch_idx"].view(-1, 1), batch["cls"].view(-1, 1), batch["bboxes"]), 1).to(dev).float()
         g = _pad_targets(rows, B, 5, imgsz[[1, 0, 1, 0]])
-        gl, gb = g.split((1, 4), 2)
-        mask_gt = (gb.sum(2, keepdim=True) > 0).float()
-        A = dist.shape[1]
-        proj = torch.arange(self.reg_max, dtype=torch.float32, device=dev)
-        d = dist.view(B, A, 4, self.reg_max).softmax(3).matmul(proj)
-        pb = torch.cat((anc - d[..., :2], anc + d[..., 2:]), -1)
-        _, t_box, t_sc, fg, gt_idx = self.assigner(sc.detach().sigmoid(), pb.detach() * st, anc * st, gl, gb, mask_gt)
-        tss = t_sc.sum().clamp(min=1)
-        l_cls = F.binary_cross_entropy_with_logits(sc, t_sc, reduction="none").sum() / tss
-        l_box = torch.zeros((), device=dev)
-        l_dfl = torch.zeros((), device=dev)
-        if fg.sum():
-            t_box = t_box / st
-            w = t_sc.sum(-1)[fg].unsqueeze(-1)
-            iou = ciou(pb[fg], t_box[fg]).unsqueeze(-1)
-            l_box = ((1.0 - iou) * w).sum() / tss
-            ltrb = torch.cat((anc - t_box[..., :2], t_box[..., 2:] - anc), -1).clamp(0, self.reg_max - 1 - 0.01)[fg]
-            pdist = dist[fg].view(-1, self.reg_max)
-            tl = ltrb.long()
-            tr = tl + 1
-            wl = tr - ltrb
-            wr = 1 - wl
-            dfl = (F.cross_entropy(pdist, tl.view(-1), reduction="none").view(tl.shape) * wl +
-                   F.cross_entropy(pdist, tr.view(-1), reduction="none").view(tl.shape) * wr).mean(-1, keepdim=True)
-            l_dfl = (dfl * w).sum() / tss
-        loss = torch.stack((l_box * self.hyp.box, l_cls * self.hyp.cls, l_dfl * self.hyp.dfl))
-        self.last_assignment = (fg, gt_idx)
-        return loss.sum() * B, loss.detach()
+        if g.shape[1] == 0:
+            # no boxes at all: background-only classification loss (loss.py:244), dense BCE against zero targets
+            sc = _flatten_maps(feats)[..., self.reg_max * 4:]
+            l_cls = F.binary_cross_entropy_with_logits(sc, torch.zeros_like(sc), reduction="none").sum() * self.hyp.cls
+            loss = torch.stack((torch.zeros((), device=dev), l_cls, torch.zeros((), device=dev)))
+            return loss.sum() * B, loss.detach()
+        h = self.hyp
+        cfg = (self.stride[: len(feats)], self.nc, self.topk, 0.5, 6.0, (float(h.box), float(h.cls), float(h.dfl)))
+        maps = [f if f.dtype == ops.compute_dtype() else f.to(ops.compute_dtype()) for f in feats]
+        total, items, fg, gt_idx, t_sc = Loss2dFn.apply(cfg, g, *maps)
+        self.last_assignment = (fg.bool(), gt_idx.long(), t_sc)
+        return total * B, items
 
 
 class v10DetectLoss:

@@ -131,6 +131,32 @@ def table_strides(model: nn.Sequential, nl=None):
     raise ValueError("no detect layer in the table")
 
 
+def fuse_conv_and_bn(w, gamma, beta, mean, var, eps=1e-3):
+    """reference utils/torch_utils.py:171-198: W' = diag(gamma / sqrt(var + eps)) W,  b' = beta - gamma * mean / sqrt(var + eps).
+    One-off host-side weight transform (deployment export); the eval path itself applies the same scale/shift in the conv
+    epilogue (y3d_conv2d_fwd_affine) and never materialises folded weights."""
+    s = gamma / torch.sqrt(var + eps)
+    return w * s.view(-1, 1, 1, 1), beta - mean * s
+
+
+def fuse_repvggdw(m, eps=1e-3):
+    """reference block.py:716-735 RepVGGDW.fuse: fold both BatchNorms and pad the 3x3 depth-wise filter into the 7x7 one"""
+    w7, b7 = fuse_conv_and_bn(m.conv.conv.weight, m.conv.bn.weight, m.conv.bn.bias, m.conv.bn.running_mean, m.conv.bn.running_var, eps)
+    w3, b3 = fuse_conv_and_bn(m.conv1.conv.weight, m.conv1.bn.weight, m.conv1.bn.bias, m.conv1.bn.running_mean, m.conv1.bn.running_var, eps)
+    return w7 + torch.nn.functional.pad(w3, [2, 2, 2, 2]), b7 + b3
+
+
+def folded_state_dict(model):
+    """{conv-key: folded weight, conv-key-with-.bias: folded bias} for every Conv of the model (BaseModel.fuse, tasks.py:177-205)"""
+    out = {}
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, Conv):
+                w, b = fuse_conv_and_bn(m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.eps)
+                out[name + ".conv.weight"], out[name + ".conv.bias"] = w, b
+    return out
+
+
 def initialize_weights(model):
     """reference utils/torch_utils.py:327-337"""
     for m in model.modules():
