@@ -57,28 +57,6 @@ def synth_batch(B, H, W, seed, device, nc=3):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
-    """reference engine/trainer.py:734-790: three parameter groups (weights with decay, BN weights, biases), SGD nesterov"""
-    g = [], [], []
-    bn = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k)
-    seen = set()
-    for mod in model.modules():
-        for pn, p in mod.named_parameters(recurse=False):
-            if id(p) in seen or not p.requires_grad:
-                continue
-            seen.add(id(p))
-            if pn == "bias":
-                g[2].append(p)
-            elif isinstance(mod, bn):
-                g[1].append(p)
-            else:
-                g[0].append(p)
-    opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
-    opt.add_param_group({"params": g[0], "weight_decay": decay})
-    opt.add_param_group({"params": g[1], "weight_decay": 0.0})
-    return opt
-
-
 def cpu_baseline(model_name, imgsz, seed, steps=2, B=2):
     """oracle restatement (fp32) timed on the host cores: fwd + loss + bwd on a bounded sample (B=2 per step)."""
     import yaml
@@ -155,7 +133,8 @@ def main():
     y3d.set_compute_dtype(dtype)
     torch.manual_seed(0)
     model = y3d.YOLOv10_3DDetectionModel(args.model).to(dev).train()
-    opt = build_optimizer(model)
+    from yolov10_3d_amd.optim import build_optimizer
+    opt = build_optimizer(model)  # reference engine/trainer.py:734-790 groups; fused clip + SGD(nesterov) HIP step
     net = model
     model.model[-1].restack()  # sibling-branch parameter stacking must be in place before DDP records parameters / buffers
     if world > 1 or os.environ.get("Y3D_FORCE_DDP"):
@@ -166,8 +145,7 @@ def main():
     def step():
         loss, items = net(batch)
         ddp.scale_loss(loss, world).backward()  # reference trainer.py:401-402 (the all-reduce averages gradients)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)  # trainer.py:570
-        opt.step()
+        opt.step(max_norm=10.0)  # clip_grad_norm_(10) + SGD nesterov (trainer.py:570-571) in three multi-tensor launches
         opt.zero_grad(set_to_none=True)
         return items
 

@@ -227,6 +227,20 @@ int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, 
 int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
                         int64_t* labels, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer step as multi-tensor launches (optim.hip): clip_grad_norm_ + SGD(nesterov, weight decay) — engine/trainer.py:567-575,
+ * 734-790.  All table arguments are DEVICE arrays: tensor t has sizes[t] fp32 elements at param_ptrs[t] / grad_ptrs[t] / buf_ptrs[t];
+ * workgroup c handles elements [chunk_off[c]*chunk, +chunk) of tensor chunk_tensor[c].
+ * ---------------------------------------------------------------------------------------------- */
+int y3d_mt_sqnorm(const int64_t* grad_ptrs, const int64_t* sizes, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk,
+                  float* partials, void* stream);
+/* out[0] = total gradient L2 norm, out[1] = min(1, max_norm / (norm + 1e-6)) */
+int y3d_mt_clip_coef(const float* partials, int nchunks, float max_norm, float* out_norm_clip, void* stream);
+/* g = grad*clip (+ wd*p); buf = first ? g : momentum*buf + g; p -= lr * (nesterov ? g + momentum*buf : buf) */
+int y3d_mt_sgd(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int64_t* buf_ptrs, const int64_t* sizes, const float* lr,
+               const float* wd, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, float momentum, int nesterov,
+               int first_step, const float* norm_clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -542,3 +542,25 @@ def test_loss2d_hip_vs_reference_golden(dtype):
     tol = 1e-3 if dtype == torch.float32 else 1e-2
     for a, b in zip(o2m + o2o, om + oo):
         check(a.grad, b.grad, tol, "d loss / d map")
+
+
+def test_fused_sgd_matches_torch():
+    """clip_grad_norm_(10) + SGD(nesterov, weight decay) as 3 multi-tensor launches vs torch's own implementation, 3 steps"""
+    from yolov10_3d_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (17,), (300000,), (5, 7), (16385,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref = torch.optim.SGD([{"params": ref[:3], "weight_decay": 5e-4}, {"params": ref[3:], "weight_decay": 0.0}], lr=0.01, momentum=0.937, nesterov=True)
+    o_my = FusedSGD([{"params": mine[:3], "weight_decay": 5e-4}, {"params": mine[3:], "weight_decay": 0.0}], lr=0.01, momentum=0.937, nesterov=True)
+    for step in range(3):
+        grads = [torch.randn_like(p) * (3.0 if step == 1 else 0.01) for p in ref]  # step 1 is clipped, the others are not
+        for p, q, g in zip(ref, mine, grads):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, max_norm=10.0)
+        o_ref.step()
+        o_my.step(max_norm=10.0)
+        check(o_my.last_norm[0:1], n_ref.reshape(1), 1e-5, "grad norm")
+        for p, q in zip(ref, mine):
+            check(q, p, 1e-6, f"param after step {step}")

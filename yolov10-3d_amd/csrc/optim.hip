@@ -1,0 +1,109 @@
+// Optimizer side of the training step as three multi-tensor launches:
+//   clip_grad_norm_(max_norm) (engine/trainer.py:570, torch.nn.utils.clip_grad_norm_) + SGD with Nesterov momentum and weight decay
+//   (trainer.py:571, build_optimizer :734-790; torch.optim.SGD semantics, dampening 0).
+// The ~570 parameter tensors are addressed through device tables (pointer, size) and a chunk table (tensor id, offset): one workgroup
+// per 16 K-element chunk, 16-byte accesses.  HBM-bound: 16 B read + 8 B written per element for the update, 4 B read for the norm.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void mt_sqnorm_kernel(const long* __restrict__ gptr, const long* __restrict__ sizes, const int* __restrict__ ctensor,
+                                                        const int* __restrict__ coff, int chunk, float* __restrict__ partials) {
+  __shared__ float sh[256];
+  const int t = ctensor[blockIdx.x];
+  const long off = (long)coff[blockIdx.x] * chunk;
+  const float* g = (const float*)gptr[t] + off;
+  long n = sizes[t] - off;
+  if (n > chunk) n = chunk;
+  float s = 0.f;
+  if ((((uintptr_t)g) & 15) == 0) {
+    long n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 v = ((const float4*)g)[i];
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+// out[0] = total L2 norm, out[1] = min(1, max_norm / (norm + 1e-6))
+__global__ __launch_bounds__(256) void mt_clip_kernel(const float* __restrict__ partials, int n, float max_norm, float* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float norm = (float)sqrt(sh[0]);
+    float c = max_norm / (norm + 1e-6f);
+    out[0] = norm;
+    out[1] = c < 1.f ? c : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void mt_sgd_kernel(const long* __restrict__ pptr, const long* __restrict__ gptr, const long* __restrict__ bptr,
+                                                     const long* __restrict__ sizes, const float* __restrict__ lr, const float* __restrict__ wd,
+                                                     const int* __restrict__ ctensor, const int* __restrict__ coff, int chunk, float momentum,
+                                                     int nesterov, int first, const float* __restrict__ clip) {
+  const int t = ctensor[blockIdx.x];
+  const long off = (long)coff[blockIdx.x] * chunk;
+  float* p = (float*)pptr[t] + off;
+  const float* g = (const float*)gptr[t] + off;
+  float* b = (float*)bptr[t] + off;
+  long n = sizes[t] - off;
+  if (n > chunk) n = chunk;
+  const float c = clip ? clip[1] : 1.f, l = lr[t], w = wd[t];
+  for (long i = threadIdx.x; i < n; i += 256) {
+    float pv = p[i];
+    float gv = g[i] * c;
+    if (w != 0.f) gv += w * pv;
+    float bv = first ? gv : momentum * b[i] + gv;
+    b[i] = bv;
+    float step = nesterov ? gv + momentum * bv : bv;
+    p[i] = pv - l * step;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_mt_sqnorm(const int64_t* grad_ptrs, const int64_t* sizes, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk,
+                  float* partials, void* stream) {
+  Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_sqnorm: empty chunk table");
+  hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)grad_ptrs, (const long*)sizes, chunk_tensor,
+                     chunk_off, chunk, partials);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_mt_clip_coef(const float* partials, int nchunks, float max_norm, float* out_norm_clip, void* stream) {
+  hipLaunchKernelGGL(mt_clip_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nchunks, max_norm, out_norm_clip);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_mt_sgd(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int64_t* buf_ptrs, const int64_t* sizes, const float* lr,
+               const float* wd, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, float momentum, int nesterov,
+               int first_step, const float* norm_clip, void* stream) {
+  Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_sgd: empty chunk table");
+  hipLaunchKernelGGL(mt_sgd_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)param_ptrs, (const long*)grad_ptrs,
+                     (const long*)buf_ptrs, (const long*)sizes, lr, wd, chunk_tensor, chunk_off, chunk, momentum, nesterov, first_step, norm_clip);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""Fused optimizer step: gradient clipping + SGD(Nesterov) over all parameters in three HIP launches.
+
+Reference recipe (engine/trainer.py:567-575): unscale -> clip_grad_norm_(max_norm=10) -> optimizer.step -> zero_grad, with the three
+parameter groups of build_optimizer (:734-790: weights with decay, norm weights without, biases without).  Semantics are
+torch.optim.SGD's (dampening 0) and torch.nn.utils.clip_grad_norm_'s.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import Y3DError, lib
+
+CHUNK = 16384
+
+
+class FusedSGD:
+    def __init__(self, param_groups, lr=0.01, momentum=0.937, nesterov=True, weight_decay=0.0):
+        if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
+            param_groups = [{"params": list(param_groups)}]
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g.setdefault("lr", lr)
+            g.setdefault("weight_decay", weight_decay)
+            g["params"] = [p for p in g["params"] if p.requires_grad]
+            self.param_groups.append(g)
+        self.momentum, self.nesterov = float(momentum), bool(nesterov)
+        self.params = [p for g in self.param_groups for p in g["params"]]
+        if not self.params:
+            raise ValueError("FusedSGD: no parameters")
+        self._state = None
+        self._steps = 0
+        self.last_norm = None
+
+    def add_param_group(self, g):
+        g = dict(g)
+        g.setdefault("lr", self.param_groups[0]["lr"])
+        g.setdefault("weight_decay", 0.0)
+        g["params"] = [p for p in g["params"] if p.requires_grad]
+        self.param_groups.append(g)
+        self.params = [p for gg in self.param_groups for p in gg["params"]]
+        self._state = None
+
+    def _build(self):
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise Y3DError("FusedSGD needs parameters on a HIP device")
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise Y3DError("FusedSGD: parameters must be contiguous fp32 tensors")
+        sizes = [p.numel() for p in self.params]
+        ct, co = [], []
+        for t, n in enumerate(sizes):
+            for c in range((n + CHUNK - 1) // CHUNK):
+                ct.append(t)
+                co.append(c)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)  # momentum buffers, one allocation
+        bufs, off = [], 0
+        for n in sizes:
+            bufs.append(flat[off:off + n])
+            off += n
+        i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+        st = {
+            "dev": dev, "flat": flat, "bufs": bufs, "nchunks": len(ct),
+            "sizes": i64(sizes), "ctensor": torch.tensor(ct, dtype=torch.int32, device=dev), "coff": torch.tensor(co, dtype=torch.int32, device=dev),
+            "bptr": i64([b.data_ptr() for b in bufs]), "partials": torch.empty(len(ct), dtype=torch.float32, device=dev),
+            "norm_clip": torch.empty(2, dtype=torch.float32, device=dev), "pkey": None, "gkey": None, "hkey": None,
+        }
+        self._state = st
+        return st
+
+    def _tables(self, st):
+        pkey = [p.data_ptr() for p in self.params]
+        if pkey != st["pkey"]:  # parameters re-pointed (e.g. sibling-branch stacking, .to()): refresh
+            st["pptr"] = torch.tensor(pkey, dtype=torch.int64, device=st["dev"])
+            st["pkey"] = pkey
+        grads = []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                raise Y3DError("FusedSGD.step: a parameter has no gradient (every YOLOv10 parameter gets one each step, SURVEY §8e)")
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = p.grad = g.float().contiguous()
+            grads.append(g)
+        gkey = [g.data_ptr() for g in grads]
+        if gkey != st["gkey"]:
+            st["gptr"] = torch.tensor(gkey, dtype=torch.int64, device=st["dev"])
+            st["gkey"] = gkey
+        hkey = [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups]
+        if hkey != st["hkey"]:
+            lr = [g["lr"] for g in self.param_groups for _ in g["params"]]
+            wd = [g["weight_decay"] for g in self.param_groups for _ in g["params"]]
+            st["lr"] = torch.tensor(lr, dtype=torch.float32, device=st["dev"])
+            st["wd"] = torch.tensor(wd, dtype=torch.float32, device=st["dev"])
+            st["hkey"] = hkey
+        return grads
+
+    @torch.no_grad()
+    def step(self, max_norm: float | None = 10.0):
+        """clip (when max_norm is given) + update; self.last_norm holds the device tensor [total_norm, clip_coef]"""
+        st = self._state or self._build()
+        self._tables(st)
+        L, s = lib(), ops.stream()
+        clip = None
+        if max_norm is not None:
+            L.mt_sqnorm(st["gptr"].data_ptr(), st["sizes"].data_ptr(), st["ctensor"].data_ptr(), st["coff"].data_ptr(), st["nchunks"], CHUNK,
+                        st["partials"].data_ptr(), s)
+            L.mt_clip_coef(st["partials"].data_ptr(), st["nchunks"], float(max_norm), st["norm_clip"].data_ptr(), s)
+            clip = st["norm_clip"].data_ptr()
+            self.last_norm = st["norm_clip"]
+        L.mt_sgd(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["sizes"].data_ptr(), st["lr"].data_ptr(),
+                 st["wd"].data_ptr(), st["ctensor"].data_ptr(), st["coff"].data_ptr(), st["nchunks"], CHUNK, self.momentum, int(self.nesterov),
+                 int(self._steps == 0), clip, s)
+        self._steps += 1
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
+    """the reference's three parameter groups (engine/trainer.py:766-790): biases, weights (decay), normalisation weights"""
+    g = [], [], []
+    bn = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k)
+    seen = set()
+    for mod in model.modules():
+        for pn, p in mod.named_parameters(recurse=False):
+            if id(p) in seen or not p.requires_grad:
+                continue
+            seen.add(id(p))
+            if pn == "bias":
+                g[2].append(p)
+            elif isinstance(mod, bn):
+                g[1].append(p)
+            else:
+                g[0].append(p)
+    return FusedSGD([{"params": g[2], "weight_decay": 0.0}, {"params": g[0], "weight_decay": decay}, {"params": g[1], "weight_decay": 0.0}],
+                    lr=lr, momentum=momentum, nesterov=True)
