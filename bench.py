@@ -210,8 +210,13 @@ def main():
             flops = 2.0 * B * P3 * P3 * 16 * mid * mid * 9
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+            traffic = None  # HBM bytes per launch of this kernel from the committed PMC passes (tools/pmc_summary.py); bench cannot run rocprof itself
+            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_headline.json")
+            if os.path.exists(pj) and dtype == torch.bfloat16 and B == 32 and S == 640:
+                with open(pj) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": "conv3x3_tile_kernel<%s,TH=16> (resident-halo implicit GEMM) 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None
         if not args.no_cpu_baseline:

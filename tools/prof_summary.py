@@ -1,5 +1,5 @@
 import csv, sys, glob
-f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")[0]
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
