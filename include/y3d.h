@@ -224,8 +224,9 @@ int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, 
                       float* y, void* stream);
 /* y (B, C, A) fp32; scores are the first nc rows (3D, boxes_first = 0) or the last nc rows (2D, boxes_first = 1).
  * reg (B, max_det, C-nc), scores (B, max_det), labels (B, max_det) int64 */
+int y3d_v10_postprocess_scratch_floats(int B, int A, int nc, int max_det); /* 0 when the score row fits LDS, else B*A */
 int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
-                        int64_t* labels, void* stream);
+                        int64_t* labels, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step as multi-tensor launches (optim.hip): clip_grad_norm_ + SGD(nesterov, weight decay) — engine/trainer.py:567-575,

@@ -137,10 +137,11 @@ __global__ void head_decode_kernel(DecL L, float* __restrict__ y, int B) {
 
 // preds y (B, C, A) fp32 with `nc` score rows first: reg (B,K,C-nc), scores (B,K), labels (B,K) int64
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first,
-                                                          float* __restrict__ reg, float* __restrict__ scores, long* __restrict__ labels) {
+                                                          float* __restrict__ reg, float* __restrict__ scores, long* __restrict__ labels,
+                                                          float* __restrict__ scratch) {
   extern __shared__ float sm[];
-  float* vals = sm;             // [A]
-  float* sv = sm + A;           // [256]
+  float* vals = scratch ? scratch + (long)blockIdx.x * A : sm;  // [A]: LDS when it fits, else the caller's HBM scratch (hi-res maps)
+  float* sv = scratch ? sm : sm + A;  // [256]
   int* si = (int*)(sv + 256);   // [256]
   int* top = si + 256;          // [K]
   float* sc2 = (float*)(top + K);  // [K*nc]
@@ -238,13 +239,20 @@ int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, 
   return Y3D_OK;
 }
 
+int y3d_v10_postprocess_scratch_floats(int B, int A, int nc, int max_det) {
+  return (size_t)(A + 512 + max_det * (nc + 3)) * 4 <= 160 * 1024 ? 0 : B * A;
+}
+
 int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
-                        int64_t* labels, void* stream) {
+                        int64_t* labels, float* scratch, void* stream) {
   Y3D_CHECK(max_det >= 1 && max_det <= A && nc >= 1 && nc < C, "v10_postprocess: bad sizes");
-  size_t sm = (size_t)(A + 512 + max_det * (nc + 3)) * 4;
-  Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: %d anchors do not fit LDS", A);
+  const bool fits = y3d_v10_postprocess_scratch_floats(B, A, nc, max_det) == 0;
+  Y3D_CHECK(fits || scratch, "v10_postprocess: %d anchors do not fit LDS and no scratch was given (y3d_v10_postprocess_scratch_floats)", A);
+  if (fits) scratch = nullptr;
+  size_t sm = (size_t)((fits ? A : 0) + 512 + max_det * (nc + 3)) * 4;
+  Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: max_det * nc = %d does not fit LDS", max_det * nc);
   (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels);
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

@@ -434,7 +434,10 @@ def _postprocess(preds, max_det, nc, boxes_first):
     reg = torch.empty(B, max_det, nr, dtype=torch.float32, device=preds.device)
     scores = torch.empty(B, max_det, dtype=torch.float32, device=preds.device)
     labels = torch.empty(B, max_det, dtype=torch.int64, device=preds.device)
-    lib().v10_postprocess(y.data_ptr(), B, C, A, nc, max_det, int(boxes_first), reg.data_ptr(), scores.data_ptr(), labels.data_ptr(), ops.stream())
+    ns = lib().v10_postprocess_scratch_floats(B, A, nc, max_det)  # hi-res maps: the per-image score row lives in HBM instead of LDS
+    scratch = torch.empty(ns, dtype=torch.float32, device=preds.device) if ns else None
+    lib().v10_postprocess(y.data_ptr(), B, C, A, nc, max_det, int(boxes_first), reg.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                          scratch.data_ptr() if ns else None, ops.stream())
     return reg, scores, labels
 
 

@@ -42,65 +42,75 @@ class FusedSGD:
         self.params = [p for gg in self.param_groups for p in gg["params"]]
         self._state = None
 
-    def _build(self):
+    def _build(self, active):
+        """tables over the parameters that carry a gradient (torch.optim.SGD and clip_grad_norm_ skip the others, e.g. the neck
+        blocks behind a detect level that `num_scales: 2` leaves unused); momentum buffers are zero-initialised, so the first
+        update `buf = momentum*0 + g` equals torch's `buf = clone(g)` exactly."""
         dev = self.params[0].device
         if dev.type != "cuda":
             raise Y3DError("FusedSGD needs parameters on a HIP device")
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise Y3DError("FusedSGD: parameters must be contiguous fp32 tensors")
-        sizes = [p.numel() for p in self.params]
+        old = self._state
+        if old is None:
+            sizes_all = [p.numel() for p in self.params]
+            flat = torch.zeros(sum(sizes_all), dtype=torch.float32, device=dev)  # momentum buffers, one allocation
+            bufs, off = [], 0
+            for n in sizes_all:
+                bufs.append(flat[off:off + n])
+                off += n
+        else:
+            flat, bufs = old["flat"], old["bufs"]
+        sizes = [self.params[i].numel() for i in active]
         ct, co = [], []
         for t, n in enumerate(sizes):
             for c in range((n + CHUNK - 1) // CHUNK):
                 ct.append(t)
                 co.append(c)
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)  # momentum buffers, one allocation
-        bufs, off = [], 0
-        for n in sizes:
-            bufs.append(flat[off:off + n])
-            off += n
         i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+        lr_all = [g["lr"] for g in self.param_groups for _ in g["params"]]
+        wd_all = [g["weight_decay"] for g in self.param_groups for _ in g["params"]]
         st = {
-            "dev": dev, "flat": flat, "bufs": bufs, "nchunks": len(ct),
+            "dev": dev, "flat": flat, "bufs": bufs, "nchunks": len(ct), "active": list(active),
             "sizes": i64(sizes), "ctensor": torch.tensor(ct, dtype=torch.int32, device=dev), "coff": torch.tensor(co, dtype=torch.int32, device=dev),
-            "bptr": i64([b.data_ptr() for b in bufs]), "partials": torch.empty(len(ct), dtype=torch.float32, device=dev),
-            "norm_clip": torch.empty(2, dtype=torch.float32, device=dev), "pkey": None, "gkey": None, "hkey": None,
+            "bptr": i64([bufs[i].data_ptr() for i in active]), "partials": torch.empty(len(ct), dtype=torch.float32, device=dev),
+            "norm_clip": torch.empty(2, dtype=torch.float32, device=dev), "pkey": None, "gkey": None,
+            "lr": torch.tensor([lr_all[i] for i in active], dtype=torch.float32, device=dev),
+            "wd": torch.tensor([wd_all[i] for i in active], dtype=torch.float32, device=dev),
+            "hkey": [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups],
         }
         self._state = st
         return st
 
-    def _tables(self, st):
-        pkey = [p.data_ptr() for p in self.params]
+    def _tables(self):
+        active = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not active:
+            raise Y3DError("FusedSGD.step: no parameter has a gradient")
+        st = self._state
+        hkey = [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups]
+        if st is None or st["active"] != active or st["hkey"] != hkey:
+            st = self._build(active)
+        pkey = [self.params[i].data_ptr() for i in active]
         if pkey != st["pkey"]:  # parameters re-pointed (e.g. sibling-branch stacking, .to()): refresh
             st["pptr"] = torch.tensor(pkey, dtype=torch.int64, device=st["dev"])
             st["pkey"] = pkey
-        grads = []
-        for p in self.params:
+        gkey = []
+        for i in active:
+            p = self.params[i]
             g = p.grad
-            if g is None:
-                raise Y3DError("FusedSGD.step: a parameter has no gradient (every YOLOv10 parameter gets one each step, SURVEY §8e)")
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = p.grad = g.float().contiguous()
-            grads.append(g)
-        gkey = [g.data_ptr() for g in grads]
+            gkey.append(g.data_ptr())
         if gkey != st["gkey"]:
             st["gptr"] = torch.tensor(gkey, dtype=torch.int64, device=st["dev"])
             st["gkey"] = gkey
-        hkey = [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups]
-        if hkey != st["hkey"]:
-            lr = [g["lr"] for g in self.param_groups for _ in g["params"]]
-            wd = [g["weight_decay"] for g in self.param_groups for _ in g["params"]]
-            st["lr"] = torch.tensor(lr, dtype=torch.float32, device=st["dev"])
-            st["wd"] = torch.tensor(wd, dtype=torch.float32, device=st["dev"])
-            st["hkey"] = hkey
-        return grads
+        return st
 
     @torch.no_grad()
     def step(self, max_norm: float | None = 10.0):
         """clip (when max_norm is given) + update; self.last_norm holds the device tensor [total_norm, clip_coef]"""
-        st = self._state or self._build()
-        self._tables(st)
+        st = self._tables()
         L, s = lib(), ops.stream()
         clip = None
         if max_norm is not None:
@@ -111,7 +121,7 @@ class FusedSGD:
             self.last_norm = st["norm_clip"]
         L.mt_sgd(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["sizes"].data_ptr(), st["lr"].data_ptr(),
                  st["wd"].data_ptr(), st["ctensor"].data_ptr(), st["coff"].data_ptr(), st["nchunks"], CHUNK, self.momentum, int(self.nesterov),
-                 int(self._steps == 0), clip, s)
+                 0, clip, s)
         self._steps += 1
 
     def zero_grad(self, set_to_none: bool = True):
