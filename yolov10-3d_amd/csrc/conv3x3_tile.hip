@@ -4,11 +4,17 @@
 // One workgroup owns TH x 16 output pixels x 128 output channels of one group.  Per 64-channel (bf16; 32 for fp32) input slab
 // the (TH+2) x 18 halo tile is brought into LDS ONCE and all nine filter taps read their shifted windows straight out of it
 // as MFMA B-operand fragments (no im2col copy anywhere, each input pixel fetched once per slab instead of nine times); the
-// 128 x 64 weight tile of the current tap streams through a second LDS ring.  Both rings are filled by LDS-DMA
-// (`global_load_lds_dwordx4`: no VGPR staging, no ds_write); the XOR swizzle that keeps `ds_read_b128` conflict-free is applied
-// on the per-lane SOURCE address (the DMA destination is lane-linear), zero padding comes from a 16-byte zero page.
-// Global->LDS traffic per workgroup is ~3x lower than the generic implicit GEMM of conv_gemm.hip (204 vs 64 FLOP/B at TH=16),
-// which moves the kernel from L1-fill-bound towards MFMA-bound.
+// 128 x 64 weight tile of each tap streams through an LDS ring (4 slots at TH=16: three taps in flight).  Both are filled by
+// LDS-DMA (`global_load_lds_dwordx4`: no VGPR staging, no ds_write); the XOR swizzle that keeps `ds_read_b128` conflict-free is
+// applied on the per-lane SOURCE address (the DMA destination is lane-linear), zero padding comes from a 16-byte zero page.
+//
+// Pipeline (one stage = one filter tap = 32 MFMAs per wave at bf16): the nine taps of a slab are unrolled, so every LDS offset
+// and every wait count is a compile-time constant.  The DMA of tap t+3 and one round of the NEXT slab's halo are issued at the
+// top of stage t; the stage ends with a COUNTED `s_waitcnt vmcnt(N)` that only retires tap t+2 (the younger loads stay in
+// flight across the raw `s_barrier`), so tap t+1's weight fragments can be prefetched during stage t like the halo fragments.
+//
+// Output channels are permuted inside the MFMA row index (row r of channel tile ct is channel (r>>2)*16 + ct*4 + (r&3)) so a
+// lane ends with 16 CONSECUTIVE channels of one pixel: two 16-byte stores per pixel row instead of eight 8-byte ones.
 //
 // The data gradient of such a conv is the same kernel on dy with the taps flipped (`flip`).
 #include "common.h"
@@ -17,13 +23,19 @@
 namespace {
 
 __device__ uint4 y3d_zero_page[4];  // zero-initialised: source of every padded / out-of-range 16-byte chunk
+#ifdef Y3D_PROBE_STAMP
+__device__ unsigned long long y3d_probe_stamps[16384 * 4];
+#define Y3D_STAMP(i) if (threadIdx.x == 0 && blockIdx.z * gridDim.x + blockIdx.x < 16384) y3d_probe_stamps[(blockIdx.z * gridDim.x + blockIdx.x) * 4 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define Y3D_STAMP(i)
+#endif
 
 struct C3P {
   const void* x;
-  const void* w;   // packed [G][Cn][9][Cg] (forward) or [G][Cn][9][Cg] of the dgrad packing; row pitch Ktot
+  const void* w;   // packed [G][Cn][9][Cg] (forward) or the dgrad packing; row pitch Ktot
   void* y;
   float* part;     // optional BN partials [B*nty*ntx][G*Cn][2]
-  const float* scale;  // optional per-channel affine (+SiLU) epilogue (eval-mode BatchNorm)
+  const float* scale;  // per-channel affine (+SiLU) epilogue (eval-mode BatchNorm), EPI = 1 only
   const float* shift;
   int act;
   long xsb, xsh, xsw, ysw;
@@ -34,8 +46,13 @@ struct C3P {
   int flip;
 };
 
-template <typename T, int TH>
-__global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// XOR value of weight-tile row n: conflict-free ds_read_b128 for the permuted row order the A fragments are read in
+__device__ __forceinline__ int wswz(int n) { return (((n >> 1) & 1) << 2) | ((4 - ((n >> 4) & 3)) & 3); }
+
+template <typename T, int TH, int EPI>
+__global__ __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) void conv3x3_tile_kernel(C3P p) {
   constexpr int CE = TT<T>::CE;
   constexpr int CSE = TT<T>::BKE;          // channels per slab (128 bytes)
   constexpr int NW = TH / 2;               // waves: (TH/4) pixel-row groups x 2 channel halves
@@ -43,18 +60,23 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
   constexpr int HWD = 18;
   constexpr int NPIX = (TH + 2) * HWD;
   constexpr int HCH = NPIX * 8;            // 16-byte chunks of one halo slab
-  constexpr int HR = (HCH + NT - 1) / NT;  // DMA rounds per halo slab
-  constexpr int HBYTES = HCH * 16;         // exact: lanes past the end of the last round are masked off
+  constexpr int HR = (HCH + NT - 1) / NT;  // DMA rounds per halo slab (the last one may be partial)
+  constexpr int HFULL = HCH / NT;          // rounds every wave takes part in (what the wait counts may rely on)
+  constexpr int HBYTES = HCH * 16;
   constexpr int WR = 1024 / NT;            // DMA rounds per 128 x 128 B weight tile
-  constexpr int TPS = TH == 16 ? 2 : 1;    // filter taps per barrier: 64 MFMAs per wave between barriers at TH=16
-  constexpr int WBYTES = TPS * 16384;
+  constexpr int RD = TH == 16 ? 4 : 2;     // weight ring slots (TH = 8 keeps two workgroups per CU instead)
+  constexpr int D = RD - 1;                // taps in flight
+  constexpr bool EARLY = RD >= 4;          // tap t+1 is published one stage early: its fragments are prefetched inside stage t
+  constexpr int KS = Frag<T>::KSUB;
+  static_assert(HR <= 7 && KS % 2 == 0, "halo rounds must be issued by stage 6; fragment double buffer needs an even step count");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sH = smem;               // [2][HBYTES]
-  char* sW = smem + 2 * HBYTES;  // [2][TPS][16 KB]
+  char* sW = smem + 2 * HBYTES;  // [RD][16 KB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wp = wave >> 1, wc = wave & 1;
   const int g = blockIdx.z;
+  Y3D_STAMP(0);
   int tc, tx, ty, b, tile_lin;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -71,6 +93,7 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ Wt = (const T*)p.w;
   const T* zero = (const T*)y3d_zero_page;
+  const int nslab = p.Cg / CSE;
 
   // ---- DMA source pointers, fixed for the whole kernel (the slab / tap offset is added per issue) -------------------------
   const T* hsrc[HR];
@@ -81,31 +104,32 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
     int hy = P / HWD, hx = P - hy * HWD;
     int yy = y0 + hy - 1, xx = x0 + hx - 1;
     bool inb = chunk < HCH && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-    hsrc[rd] = inb ? X + (long)b * p.xsb + (long)yy * p.xsh + (long)xx * p.xsw + (long)g * p.Cg + ((s ^ (P & 7)) * CE) : nullptr;
+    hsrc[rd] = inb ? X + (long)b * p.xsb + (long)yy * p.xsh + (long)xx * p.xsw + (long)g * p.Cg + ((s ^ (hx & 7)) * CE) : nullptr;
   }
   const T* wsrc[WR];
 #pragma unroll
   for (int rd = 0; rd < WR; ++rd) {
     int chunk = rd * NT + tid;
     int n = chunk >> 3, s = chunk & 7;
-    wsrc[rd] = (c0 + n < p.Cn) ? Wt + ((long)(g * p.Cn + c0 + n)) * p.Ktot + ((s ^ (n & 7)) * CE) : nullptr;
+    wsrc[rd] = (c0 + n < p.Cn) ? Wt + ((long)(g * p.Cn + c0 + n)) * p.Ktot + ((s ^ wswz(n)) * CE) : nullptr;
   }
-  auto issue_w = [&](int lin, char* dstbase) {  // lin = slab * 9 + tap
-    const int slab = lin / 9, tap = lin - slab * 9;
+  // every wave issues exactly WR instructions per call (the wait counts depend on it); steps past the end read the zero page
+  auto issue_w = [&](int slab, int tap, int slot) {
     const long off = (long)(p.flip ? 8 - tap : tap) * p.Cg + (long)slab * CSE;
+    const bool live = slab < nslab;
 #pragma unroll
     for (int rd = 0; rd < WR; ++rd) {
-      const T* src = wsrc[rd] ? wsrc[rd] + off : zero;
+      const T* src = (live && wsrc[rd]) ? wsrc[rd] + off : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dstbase + (rd * NT + wave * 64) * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sW + slot * 16384 + (rd * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
-  auto issue_h = [&](int slab, int buf, int rd) {
-    // rd is wave-uniform; lanes past the end of the image of the last round are masked off
+  auto issue_h = [&](int slab, int rd) {
+    // rd is a compile-time constant after unrolling; in the last (partial) round the lanes past the end are masked off
     if (rd * NT + tid < HCH) {
-      const T* src = hsrc[rd] ? hsrc[rd] + (long)slab * CSE : zero;
+      const T* src = (slab < nslab && hsrc[rd]) ? hsrc[rd] + (long)slab * CSE : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sH + buf * HBYTES + (rd * NT + wave * 64) * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sH + (slab & 1) * HBYTES + (rd * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -115,146 +139,146 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nslab = p.Cg / CSE;
-  const int S = nslab * 9;  // linear (slab, tap) steps
+  // ---- fragment addressing: a lane-dependent byte offset per (column shift q | K sub-step) + compile-time immediates ------------
+  // halo rows are swizzled by their COLUMN (hx & 7): the 16 pixels of a fragment are 16 consecutive columns of one halo row
+  const int lp16 = lane & 15;
+  const int arow = wc * 64 + (lp16 >> 2) * 16 + (lp16 & 3);  // + ct * 4: weight-tile row of this lane's A-fragment row
+  int bo[3][KS], ao[KS];
 #pragma unroll
-  for (int rd = 0; rd < HR; ++rd) issue_h(0, 0, rd);
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-  for (int t = 0; t < TPS; ++t)
-    if (t < S) issue_w(t, sW + t * 16384);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // Fragments are double buffered by hand: while the 16 MFMAs of one K sub-step run, the LDS reads of the next sub-step are
-  // already in flight (also across taps and, for the halo operand, across the barrier: the halo slab is stable within a slab).
-  // Only the four weight fragments of a stage's first sub-step wait for the barrier that publishes the DMA.
-  constexpr int KS = Frag<T>::KSUB;
+    for (int q = 0; q < 3; ++q) bo[q][ks] = (4 * wp * HWD + q + lp16) * 128 + Frag<T>::coff(ks, lane, (q + lp16) & 7);
+    ao[ks] = arow * 128 + Frag<T>::coff(ks, lane, wswz(arow));  // wswz(arow + ct * 4) == wswz(arow)
+  }
   typename Frag<T>::type fb[2][4], fa[2][4];
-  auto load_b = [&](typename Frag<T>::type* dst, int lin, int ks) {
-    const int slab = lin / 9, tap = lin - slab * 9;
+  auto load_b = [&](typename Frag<T>::type* dst, int slab, int tap, int ks) {
     const int r = tap / 3, q = tap - r * 3;
-    const char* hb = sH + (slab & 1) * HBYTES;
+    const char* hb = sH + (slab & 1) * HBYTES + bo[q][ks];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) dst[pt] = Frag<T>::load(hb, (4 * wp + pt + r) * HWD + q, ks, lane);
+    for (int pt = 0; pt < 4; ++pt) dst[pt] = Frag<T>::ld(hb + (pt + r) * (HWD * 128));
   };
-  auto load_a = [&](typename Frag<T>::type* dst, const char* wb, int ks) {
+  auto load_a = [&](typename Frag<T>::type* dst, int slot, int ks) {
+    const char* wb = sW + slot * 16384 + ao[ks];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) dst[ct] = Frag<T>::load(wb, wc * 64 + ct * 16, ks, lane);
+    for (int ct = 0; ct < 4; ++ct) dst[ct] = Frag<T>::ld(wb + ct * 512);
   };
-  load_b(fb[0], 0, 0);
-  int hslab = 0, hrd = 0;  // slab whose halo is being streamed in, next DMA round
-  for (int s0 = 0, stg = 0; s0 < S; s0 += TPS, ++stg) {
-    // prefetch the next stage's weight tiles; bring in the next slab's halo as soon as its buffer is free
-    char* wnext = sW + ((stg + 1) & 1) * WBYTES;
+
+  // ---- prologue: halo of slab 0, taps 0 .. D-1 ------------------------------------------------------------------------------
 #pragma unroll
-    for (int t = 0; t < TPS; ++t)
-      if (s0 + TPS + t < S) issue_w(s0 + TPS + t, wnext + t * 16384);
-    {
-      // every tap of this stage lies in slab >= k, so slab k-1's halo buffer is free: stream slab k+1's halo into it, a few
-      // DMA rounds per stage (all rounds have landed at least one stage before the first tap of slab k+1 is prefetched)
-      const int k = s0 / 9;
-      if (k + 1 < nslab) {
-        if (hslab != k + 1) { hslab = k + 1; hrd = 0; }
-        constexpr int RPS = TPS == 2 ? (HR + 2) / 3 : (HR + 5) / 6;
+  for (int rd = 0; rd < HR; ++rd) issue_h(0, rd);
 #pragma unroll
-        for (int rd = 0; rd < HR; ++rd)
-          if (rd >= hrd && rd < hrd + RPS) issue_h(k + 1, (k + 1) & 1, rd);
-        hrd += RPS;
+  for (int t = 0; t < D; ++t) issue_w(t / 9, t % 9, t % RD);
+  wait_vm<EARLY ? (D - 2) * WR : (D - 1) * WR>();  // halo + tap 0 (+ tap 1 when it is read inside stage 0)
+  __builtin_amdgcn_s_barrier();
+  Y3D_STAMP(1);
+  load_b(fb[0], 0, 0, 0);
+  if (EARLY) load_a(fa[0], 0, 0);
+
+#pragma unroll 1
+  for (int k = 0; k < nslab; ++k) {
+    const int kr = RD == 4 ? (k & 3) : (k & 1);  // ring slot of (k, tap) = (k * 9 + tap) % RD = (kr + tap) % RD  (9 % 4 == 1 % 2 == 1)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      // ---- issue: one halo round of the next slab (its buffer was last read in slab k-1), then the weights of tap t+D ------
+#ifndef Y3D_PROBE_NODMA
+      if (t < HR) issue_h(k + 1, t);
+      {
+        const int t2 = t + D;
+        issue_w(t2 < 9 ? k : k + 1, t2 < 9 ? t2 : t2 - 9, (kr + t2) % RD);
       }
-    }
-    const char* wb = sW + (stg & 1) * WBYTES;
-    load_a(fa[0], wb, 0);
+#endif
+      const int slot = (kr + t) % RD;
+      if (!EARLY) load_a(fa[0], slot, 0);
 #pragma unroll
-    for (int step = 0; step < TPS * KS; ++step) {
-      const int t = step / KS, ks = step - t * KS;
-      const int cur = step & 1, nxt = cur ^ 1;
-      if (s0 + t < S) {  // uniform: the last stage may hold fewer taps
+      for (int ks = 0; ks < KS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
         if (ks + 1 < KS) {
-          load_b(fb[nxt], s0 + t, ks + 1);
-          load_a(fa[nxt], wb + t * 16384, ks + 1);
-        } else if (t + 1 < TPS) {
-          if (s0 + t + 1 < S) {
-            load_b(fb[nxt], s0 + t + 1, 0);
-            load_a(fa[nxt], wb + (t + 1) * 16384, 0);
-          }
-        } else if (s0 + TPS < S) {
-          load_b(fb[nxt], s0 + TPS, 0);  // first sub-step of the next stage: halo operand only
+          load_b(fb[nxt], k, t, ks + 1);
+          load_a(fa[nxt], slot, ks + 1);
+        } else {
+          // first sub-step of the next tap: the halo operand is stable (the next slab's halo was retired by an earlier stage's
+          // wait); the weight operand only when its tap was published by the previous stage's barrier
+          if (t < 8) load_b(fb[nxt], k, t + 1, 0); else load_b(fb[nxt], k + 1, 0, 0);
+          if (EARLY) load_a(fa[nxt], (kr + t + 1) % RD, 0);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = Frag<T>::mma(fa[cur][ct], fb[cur][pt], acc[ct][pt]);
-      }
-    }
-    if ((TPS * KS) & 1) {
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt) fb[0][pt] = fb[1][pt];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue: store, optional BN partial sums over the valid pixels -----------------------------------------------------
-  T* __restrict__ Y = (T*)p.y;
-  const int lc = (lane >> 4) * 4, lp = lane & 15;
-  const bool xok = x0 + lp < p.W;
-  float ssum[4][4], ssq[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    const int co = c0 + wc * 64 + ct * 16 + lc;
-    float sv[4] = {1.f, 1.f, 1.f, 1.f}, hv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (co + j < p.Cn) { sv[j] = p.scale[g * p.Cn + co + j]; hv[j] = p.shift[g * p.Cn + co + j]; }
-    }
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      const int yy = y0 + 4 * wp + pt;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float u = acc[ct][pt][j];
-        if (p.scale) { u = u * sv[j] + hv[j]; if (p.act) u = silu_f(u); }
-        v[j] = xok ? TT<T>::rnd(u) : 0.f;
-        ssum[ct][j] += v[j];
-        ssq[ct][j] += v[j] * v[j];
-      }
-      if (xok) {
-        T* dst = Y + (((long)b * p.H + yy) * p.W + x0 + lp) * p.ysw + (long)g * p.Cn + co;
-        if (co + 3 < p.Cn) {
-          if (sizeof(T) == 2) {
-            uint2 u;
-            u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-            *(uint2*)dst = u;
-          } else {
-            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          for (int pt = 0; pt < 4; ++pt) {
+#ifdef Y3D_PROBE_NOMFMA
+            asm volatile("" ::"v"(fa[cur][ct]), "v"(fb[cur][pt]));
+#else
+            acc[ct][pt] = Frag<T>::mma(fa[cur][ct], fb[cur][pt], acc[ct][pt]);
+#endif
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if (co + j < p.Cn) TT<T>::st(dst + j, v[j]);
-        }
       }
+      // ---- retire tap t+1 (t+2 when EARLY): everything issued after it may stay in flight across the barrier -------------------
+      // EARLY: tap t+2 was issued in stage t-1; younger: this stage's halo round (full rounds only) + this stage's weights
+      if (EARLY) {
+        if (t < HFULL) wait_vm<WR + 1>(); else wait_vm<WR>();
+      } else {
+        wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
     }
   }
-  if (p.part) {
-    float* red = (float*)smem;  // [NW/2][128][2]; every LDS tile read finished at the last barrier
+  wait_vm<0>();  // the dummy loads past the end must land before the LDS is reused or the workgroup retires
+
+  // ---- epilogue: this lane holds channels cb .. cb+15 of pixel (y0 + 4 wp + pt, x0 + lp) ------------------------------------
+  Y3D_STAMP(2);
+  T* __restrict__ Y = (T*)p.y;
+  const int lq = lane >> 4, lp = lane & 15;
+  const int cl = wc * 64 + lq * 16;  // first of this lane's 16 channels inside the 128-channel tile
+  const bool cok = c0 + cl < p.Cn;   // Cn % 16 == 0
+  const bool xok = x0 + lp < p.W;
+  float ssum[16], ssq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+  float sv[16], hv[16];
+  if (EPI == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sv[i] = cok ? p.scale[g * p.Cn + c0 + cl + i] : 1.f; hv[i] = cok ? p.shift[g * p.Cn + c0 + cl + i] : 0.f; }
+  }
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    const int yy = y0 + 4 * wp + pt;
+    float v[16];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float s = wave_xor_sum16(ssum[ct][j]);
-        float q2 = wave_xor_sum16(ssq[ct][j]);
-        if (lp == 0) {
-          int cl = wc * 64 + ct * 16 + lc + j;
-          red[(wp * 128 + cl) * 2 + 0] = s;
-          red[(wp * 128 + cl) * 2 + 1] = q2;
-        }
+        float u = acc[ct][pt][j];
+        if (EPI == 1) { u = u * sv[ct * 4 + j] + hv[ct * 4 + j]; if (p.act) u = silu_f(u); }
+        u = xok ? TT<T>::rnd(u) : 0.f;
+        v[ct * 4 + j] = u;
+        if (EPI == 0) { ssum[ct * 4 + j] += u; ssq[ct * 4 + j] += u * u; }
       }
+#ifdef Y3D_PROBE_NOEPI
+    if (xok && cok && v[0] == 123.456f) {
+#else
+    if (xok && cok) {
+#endif
+      T* dst = Y + (((long)b * p.H + yy) * p.W + x0 + lp) * p.ysw + (long)g * p.Cn + c0 + cl;
+      if (sizeof(T) == 2) {
+        ((uint4*)dst)[0] = Chunk<T>::pack(v);
+        ((uint4*)dst)[1] = Chunk<T>::pack(v + 8);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ((uint4*)dst)[i] = Chunk<T>::pack(v + 4 * i);
+      }
+    }
+  }
+  if (EPI == 0 && p.part) {
+    float* red = (float*)smem;  // [NW/2][128][2]; all LDS tile reads finished before the last barrier
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = wave_xor_sum16(ssum[i]);
+      float q2 = wave_xor_sum16(ssq[i]);
+      if (lp == i) {  // spread the 16 writes over the 16 lanes of the row
+        red[(wp * 128 + cl + i) * 2 + 0] = s;
+        red[(wp * 128 + cl + i) * 2 + 1] = q2;
+      }
+    }
     __syncthreads();
     if (tid < 128 && c0 + tid < p.Cn) {
       float s = 0.f, q2 = 0.f;
@@ -265,36 +289,42 @@ __global__ __launch_bounds__(TH * 32) void conv3x3_tile_kernel(C3P p) {
       dst[1] = q2;
     }
   }
+  Y3D_STAMP(3);
 }
 
-template <typename T, int TH>
+template <typename T, int TH, int EPI>
 int launch_tile(const C3P& p, hipStream_t st) {
   constexpr int NW = TH / 2, NT = NW * 64;
   constexpr int HCH = (TH + 2) * 18 * 8;
-  size_t sm = 2 * (size_t)HCH * 16 + 2 * (size_t)(TH == 16 ? 2 : 1) * 16384;
+  constexpr int RD = TH == 16 ? 4 : 2;
+  size_t sm = 2 * (size_t)HCH * 16 + (size_t)RD * 16384;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    (void)hipFuncSetAttribute((const void*)conv3x3_tile_kernel<T, TH, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     attr_set = true;
   }
   dim3 grid(p.B * p.nty * p.ntx * p.ntc, 1, p.G);
-  hipLaunchKernelGGL((conv3x3_tile_kernel<T, TH>), grid, dim3(NT), sm, st, p);
+  hipLaunchKernelGGL((conv3x3_tile_kernel<T, TH, EPI>), grid, dim3(NT), sm, st, p);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
+}
+
+template <typename T, int TH>
+int launch_tile_epi(const C3P& p, hipStream_t st) {
+  return p.scale ? launch_tile<T, TH, 1>(p, st) : launch_tile<T, TH, 0>(p, st);
 }
 
 }  // namespace
 
 // tile height the resident-halo kernel would use for this geometry, 0 if the generic implicit GEMM must be used
-int y3d_tile_height(int dtype, int H, int W, int Cg, int kh, int kw, int stride, int pad) {
+int y3d_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad) {
   int cse = dtype == Y3D_BF16 ? 64 : 32;
   if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return 0;
-  if (Cg % cse != 0) return 0;
+  if (Cg % cse != 0 || Cn % 16 != 0) return 0;
   if (W < 8) return 0;
   if (H % 16 == 0) return 16;
   if (H % 8 == 0) return 8;
-  // TH = 4 (two waves per workgroup) is built and tested but measured slower than the generic implicit GEMM on 20x20 maps
-  // (262 vs 691 TFLOP/s, 512->2048, B=32): too few waves per CU to hide the DMA / LDS latency
+  // smaller tiles (two waves per workgroup) measured slower than the generic implicit GEMM on 20x20 maps
   return 0;
 }
 
@@ -307,12 +337,6 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
   p.ntx = cdiv(W, 16); p.nty = H / th; p.ntc = cdiv(Cn, 128); p.flip = flip;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == Y3D_BF16) {
-    if (th == 16) return launch_tile<bf16_t, 16>(p, st);
-    if (th == 8) return launch_tile<bf16_t, 8>(p, st);
-    return launch_tile<bf16_t, 4>(p, st);
-  }
-  if (th == 16) return launch_tile<float, 16>(p, st);
-  if (th == 8) return launch_tile<float, 8>(p, st);
-  return launch_tile<float, 4>(p, st);
+  if (dtype == Y3D_BF16) return th == 16 ? launch_tile_epi<bf16_t, 16>(p, st) : launch_tile_epi<bf16_t, 8>(p, st);
+  return th == 16 ? launch_tile_epi<float, 16>(p, st) : launch_tile_epi<float, 8>(p, st);
 }
