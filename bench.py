@@ -215,7 +215,7 @@ def main():
             if os.path.exists(pj) and dtype == torch.bfloat16 and B == 32 and S == 640:
                 with open(pj) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "conv3x3_tile_kernel<%s,TH=16> (resident-halo implicit GEMM) 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
+            roof = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<TH=16> %s (persistent resident-halo implicit GEMM) 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None

@@ -1,6 +1,7 @@
 // Stand-alone timing probe for the resident-halo 3x3 kernel on the headline shape (16 groups of 128->128 @80x80, B=32, bf16).
 // Built in variants (-DY3D_PROBE_NODMA / _NOMFMA / _NOLDS) to see which resource bounds the loop.  Not part of the library.
 #include "../../yolov10-3d_amd/csrc/conv3x3_tile.hip"
+#include "../../yolov10-3d_amd/csrc/conv3x3_wide.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,19 @@ int main(int argc, char** argv) {
     double a = 0, b = 0, c = 0; unsigned long long lo = ~0ull, hi = 0;
     for (int i = 0; i < nwg; ++i) { a += st[i*4+1] - st[i*4]; b += st[i*4+2] - st[i*4+1]; c += st[i*4+3] - st[i*4+2]; if (st[i*4] < lo) lo = st[i*4]; if (st[i*4+3] > hi) hi = st[i*4+3]; }
     printf("stamps (s_memtime ticks, 100 MHz?): prologue %.0f  loop %.0f  epilogue %.0f  per WG; kernel span %llu ticks; sum/256 CUs = %.0f\n", a / nwg, b / nwg, c / nwg, hi - lo, (a + b + c) / 256);
+  }
+#endif
+#ifdef Y3D_PROBE_TRACE
+  {
+    std::vector<unsigned> tr(2 * 18 * 6);
+    hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(y3d_probe_trace), tr.size() * 4);
+    for (int w = 0; w < 2; ++w) {
+      printf("wave %d (%s role): per stage: issue | half0 | half1 | wait | barrier   (cycles)\n", w * 4, w ? "weights" : "halo");
+      for (int st = 0; st < 18; ++st) {
+        unsigned* q = &tr[(w * 18 + st) * 6];
+        printf("  st %2d @%7u: %5u %5u %5u %5u %5u  total %5u\n", st, q[0] - tr[0], q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+      }
+    }
   }
 #endif
   printf("%s H=%d G=%d C=%d th=%d: %.3f ms  %.1f TFLOP/s\n", argv[0], H, G, Cg, th, ms, fl / ms / 1e9);

@@ -316,11 +316,15 @@ int launch_tile_epi(const C3P& p, hipStream_t st) {
 
 }  // namespace
 
-// tile height the resident-halo kernel would use for this geometry, 0 if the generic implicit GEMM must be used
+// conv3x3_wide.hip: the bf16 production kernel (persistent, 512-pixel tiles); this file's kernel stays as the fp32 (parity mode) path
+int y3d_conv3x3_wide_launch(int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w,
+                            int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream);
+
+// tile height the resident-halo kernels would use for this geometry, 0 if the generic implicit GEMM must be used
 int y3d_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad) {
-  int cse = dtype == Y3D_BF16 ? 64 : 32;
+  int cse = 32;  // channels per K slab: 32 bf16 (64-byte rows, wide kernel) or 32 fp32 (128-byte rows)
   if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return 0;
-  if (Cg % cse != 0 || Cn % 16 != 0) return 0;
+  if (Cg % cse != 0 || Cg < 64 || Cn % 16 != 0) return 0;
   if (W < 8) return 0;
   if (H % 16 == 0) return 16;
   if (H % 8 == 0) return 8;
@@ -337,6 +341,6 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
   p.ntx = cdiv(W, 16); p.nty = H / th; p.ntc = cdiv(Cn, 128); p.flip = flip;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == Y3D_BF16) return th == 16 ? launch_tile_epi<bf16_t, 16>(p, st) : launch_tile_epi<bf16_t, 8>(p, st);
+  if (dtype == Y3D_BF16) return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
   return th == 16 ? launch_tile_epi<float, 16>(p, st) : launch_tile_epi<float, 8>(p, st);
 }
