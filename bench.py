@@ -187,7 +187,7 @@ def main():
     model.eval()
     infer_ips = None
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(2 if args.infer_steps > 0 else 0):
             y = model(batch["img"])["one2one"][0]
             v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
         sync()
@@ -199,8 +199,8 @@ def main():
         ti = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(ti, op=dist.ReduceOp.MAX)
-        infer_ips = world * B * args.infer_steps / float(ti)
-    log(f"infer: {infer_ips:.1f} images/s")
+        infer_ips = world * B * args.infer_steps / float(ti) if args.infer_steps > 0 else None
+    log(f"infer: {infer_ips:.1f} images/s" if infer_ips else "infer: skipped")
 
     if rank == 0:
         res = timer.results().get(k1_key, [])

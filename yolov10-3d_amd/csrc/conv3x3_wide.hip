@@ -28,8 +28,9 @@
 // tolerates them in the vmcnt FIFO).  XCD x walks a contiguous run of tiles, its workgroups interleaved, so the tiles in flight
 // share weights and halos in that XCD's L2.
 //
-// Output channels are permuted inside the MFMA row index (row r of channel tile ct is channel (r>>2)*16 + ct*4 + (r&3)), so a
-// lane ends with 16 consecutive channels of a pixel: 16-byte stores.  The epilogue also emits the per-tile BatchNorm partial
+// Output channels are permuted inside the MFMA row index (row r of channel tile ct is channel (ct>>1)*32 + (r>>2)*8 + (ct&1)*4 +
+// (r&3)), so a lane ends with two runs of 8 consecutive channels and one store instruction writes 64 contiguous bytes per pixel
+// (with 16-byte pieces at a 32-byte stride the L2 wrote 1.8x the tensor: PMC WRITE_SIZE).  The epilogue also emits the per-tile BatchNorm partial
 // sums (sum, sum of squares of the ROUNDED outputs) or applies the eval-mode affine + SiLU.
 // The data gradient of such a conv is the same kernel on dy with the taps flipped (`flip`).
 // Register budget: 128 accumulators + 48 fragment registers leave ~60 for everything else at two waves per SIMD; the DMA
@@ -177,7 +178,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
                                                inb ? off : OOB, 0, 0, 0);
   };
-  // weights: chunk = rd * LH + ltid -> tile row n = chunk / 4 (output channel), piece s; rows swizzled by piece ^= 2 * bit5(n).
+  // weights: chunk = rd * LH + ltid -> tile row n = chunk / 4 (output channel), piece s; rows swizzled by piece ^= 2 * bit4(n).
   // Two DMA instructions per tap, always (the wait counts depend on it).
   auto issue_w = [&](const TileC& c, int slab, int tap, int slot) {
     const unsigned base = (unsigned)((c.g * p.Cn + c.c0) * p.Ktot + (p.flip ? 8 - tap : tap) * p.Cg + slab * 32) * 2u;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
       const int chunk = rd * LH + l, n = chunk >> 2, s = chunk & 3;
-      const unsigned wrel = (unsigned)(n * p.Ktot + ((s ^ (((n >> 5) & 1) << 1)) << 3)) * 2u;  // recomputed: no resident registers
+      const unsigned wrel = (unsigned)(n * p.Ktot + ((s ^ (((n >> 4) & 1) << 1)) << 3)) * 2u;  // recomputed: no resident registers
       const bool ok = (c.live != 0) & (c.c0 + n < p.Cn);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sW + slot * WB + (rd * LH + (wave - 4) * 64) * 16), 16,
                                                ok ? base + wrel : OOB, 0, 0, 0);
@@ -202,8 +203,8 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 
   // ---- fragment addressing -------------------------------------------------------------------------------------------------------
   const int lp = lane & 15, lq = lane >> 4;
-  const int arow = wc * 64 + (lp >> 2) * 16 + (lp & 3);  // + ct * 4
-  const int ao = arow * 64 + ((lq ^ (((arow >> 5) & 1) << 1)) << 4);
+  const int arow = wc * 64 + (lp >> 2) * 8 + (lp & 3);  // + (ct >> 1) * 32 + (ct & 1) * 4  (bit 4 of the row does not depend on ct)
+  const int ao = arow * 64 + ((lq ^ (((arow >> 4) & 1) << 1)) << 4);
   int bo[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) bo[q] = ((wimg * NPIX + wrow0 * HWD + q + lp) << 6) + ((lq ^ ((((q + lp) >> 2) & 1) << 1)) << 4);
@@ -214,7 +215,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = ldf(hb + (half * 4 + i + r) * (HWD * 64));
   };
-  auto load_a1 = [&](int slot, int ct) { return ldf(sW + slot * WB + ao + ct * 256); };
+  auto load_a1 = [&](int slot, int ct) { return ldf(sW + slot * WB + ao + (ct >> 1) * 2048 + (ct & 1) * 256); };
 
   // ---- prologue: halo of the first HD slabs, taps 0 .. D-1 -----------------------------------------------------------------------
   TileC cur = decode(tile, true);
@@ -280,6 +281,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         TRC(1);
         // ---- half 0: pixel rows 0..3 while rows 4..7 of this tap are fetched --------------------------------------------------------
         load_b(fb[1], hb_cur, t, 1);
+        __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together and ahead of the partner wave's VALU / DMA issue (+2 %)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -290,6 +292,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
             acc[ct][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[0][i], acc[ct][i], 0, 0, 0);
 #endif
           }
+        __builtin_amdgcn_s_setprio(0);
         // ---- half 1: rows 4..7 while the first fragments of the next stage are fetched (its tap was published one barrier ago);
         // the weight fragments are refreshed IN PLACE, each right behind the last MFMA that reads it (no second buffer: the
         // 128 accumulators leave no room for one) ------------------------------------------------------------------------------------
@@ -338,21 +341,21 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
       }
     }
 
-    // ---- epilogue: this lane holds channels cl .. cl+15 of pixels (wrow0 + pt, lp) of image b0 + wimg -----------------------------
-    const int cl = wc * 64 + lq * 16;
+    // ---- epilogue: this lane holds channels cl .. cl+7 (pass h) of pixels (wrow0 + pt, lp) of image b0 + wimg ---------------------
     const int bb = cur.b0 + wimg;
-    const bool cok = cur.c0 + cl < p.Cn && bb < p.B;  // Cn % 16 == 0
     const bool xok = cur.x0 + lp < p.W;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // two passes of 8 channels keep the live set small next to the 128 accumulators
+      const int cl = wc * 64 + h * 32 + lq * 8;
+      const bool cok = cur.c0 + cl < p.Cn && bb < p.B;  // Cn % 16 == 0
       float ssum[8], ssq[8], sv[8], hv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
       if (EPI == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          sv[i] = cok ? p.scale[cur.g * p.Cn + cur.c0 + cl + h * 8 + i] : 1.f;
-          hv[i] = cok ? p.shift[cur.g * p.Cn + cur.c0 + cl + h * 8 + i] : 0.f;
+          sv[i] = cok ? p.scale[cur.g * p.Cn + cur.c0 + cl + i] : 1.f;
+          hv[i] = cok ? p.shift[cur.g * p.Cn + cur.c0 + cl + i] : 0.f;
         }
       }
 #pragma unroll
@@ -374,7 +377,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #else
         if (xok && cok) {
 #endif
-          bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl + h * 8;
+          bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl;
           *(uint4*)dst = Chunk<bf16_t>::pack(v);
         }
       }
@@ -385,8 +388,8 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
           float s = wave_xor_sum16(ssum[i]);
           float q2 = wave_xor_sum16(ssq[i]);
           if (lp == i) {
-            red[(wp * 128 + cl + h * 8 + i) * 2 + 0] = s;
-            red[(wp * 128 + cl + h * 8 + i) * 2 + 1] = q2;
+            red[(wp * 128 + cl + i) * 2 + 0] = s;
+            red[(wp * 128 + cl + i) * 2 + 1] = q2;
           }
         }
       }
