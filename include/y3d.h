@@ -108,8 +108,8 @@ int y3d_bn_eval_scale(int C, const float* gamma, const float* beta, const float*
 /* u = y*scale+shift (+res if res_mode==2); z = act ? silu(u) : u; (+res if res_mode==1) */
 int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, const float* shift, int act, int res_mode,
                    const void* res, int64_t rsw, void* z, int64_t zsw, int64_t P, int C, void* stream);
-int y3d_bn_bwd_blocks(int64_t P);
-/* pass 1: partials [y3d_bn_bwd_blocks(P)][C][2] = (sum g, sum g*xhat), g = dz * act'(u) */
+int y3d_bn_bwd_blocks(int64_t P, int C);
+/* pass 1: partials [y3d_bn_bwd_blocks(P, C)][C][2] = (sum g, sum g*xhat), g = dz * act'(u) */
 int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,
                           const float* scale, const float* shift, const float* mean, const float* invstd, int act,
                           int res_mode, float* partials, int64_t P, int C, void* stream);
@@ -121,7 +121,7 @@ int y3d_bn_act_bwd_apply(int dtype, const void* y, int64_t ysw, const void* dz, 
                          const float* scale, const float* shift, const float* mean, const float* invstd,
                          const float* mean_g, const float* mean_gx, int act, int res_mode, int train, void* dy, int64_t dysw,
                          void* dres, int64_t drsw, int64_t P, int C, void* stream);
-/* column sums of a [P][C] tensor as partials [y3d_bn_bwd_blocks(P)][C][2] (bias gradients; reduce with y3d_bn_bwd_finalize) */
+/* column sums of a [P][C] tensor as partials [y3d_bn_bwd_blocks(P, C)][C][2] (bias gradients; reduce with y3d_bn_bwd_finalize) */
 int y3d_colsum_partials(int dtype, const void* x, int64_t xsw, float* partials, int64_t P, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -60,27 +60,46 @@ __global__ void bn_eval_scale_kernel(int C, const float* __restrict__ gamma, con
 }
 
 template <typename T, int ACT, int RES>  // RES: 0 none, 1 post-activation, 2 pre-activation
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y, long ysw, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  const T* __restrict__ res, long rsw, T* __restrict__ z, long zsw, long P, int C) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, long ysw, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const T* __restrict__ res, long rsw, T* __restrict__ z, long zsw, long P,
+                                  int C, int px_per_block) {
+  // channel-stationary: a block owns a 64-channel slab and a run of pixels, scale/shift live in registers, two pixels in flight
   constexpr int CE = TT<T>::CE;
-  const int cpr = C / CE;
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = P * cpr;
-  for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long px = idx / cpr;
-    int c = (int)(idx - px * cpr) * CE;
+  constexpr int CT = 64 / CE, PT = 256 / CT;
+  const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+  const int c = blockIdx.y * 64 + ct * CE;
+  if (c >= C) return;
+  float sc[CE], sf[CE];
+#pragma unroll
+  for (int j = 0; j < CE; ++j) { sc[j] = scale[c + j]; sf[j] = shift[c + j]; }
+  const long pbeg = (long)blockIdx.x * px_per_block;
+  const long pend = pbeg + px_per_block < P ? pbeg + px_per_block : P;
+  auto one = [&](long px, const uint4& yv, const uint4& rv) {
     float v[CE], r[CE];
-    Chunk<T>::unpack(*(const uint4*)(y + px * ysw + c), v);
-    if (RES) Chunk<T>::unpack(*(const uint4*)(res + px * rsw + c), r);
+    Chunk<T>::unpack(yv, v);
+    if (RES) Chunk<T>::unpack(rv, r);
 #pragma unroll
     for (int j = 0; j < CE; ++j) {
-      float u = v[j] * scale[c + j] + shift[c + j];
+      float u = v[j] * sc[j] + sf[j];
       if (RES == 2) u += r[j];
       if (ACT) u = silu_f(u);
       if (RES == 1) u += r[j];
       v[j] = u;
     }
     *(uint4*)(z + px * zsw + c) = Chunk<T>::pack(v);
+  };
+  long px = pbeg + pt;
+  for (; px + PT < pend; px += 2 * PT) {
+    const uint4 y0 = *(const uint4*)(y + px * ysw + c), y1 = *(const uint4*)(y + (px + PT) * ysw + c);
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    if (RES) { r0 = *(const uint4*)(res + px * rsw + c); r1 = *(const uint4*)(res + (px + PT) * rsw + c); }
+    one(px, y0, r0);
+    one(px + PT, y1, r1);
+  }
+  if (px < pend) {
+    uint4 r0 = make_uint4(0, 0, 0, 0);
+    if (RES) r0 = *(const uint4*)(res + px * rsw + c);
+    one(px, *(const uint4*)(y + px * ysw + c), r0);
   }
 }
 
@@ -106,11 +125,11 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, cons
     for (int j = 0; j < CE; ++j) { sc[j] = scale[c + j]; sf[j] = shift[c + j]; mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
     long pbeg = (long)blockIdx.x * px_per_block;
     long pend = pbeg + px_per_block < P ? pbeg + px_per_block : P;
-    for (long px = pbeg + pt; px < pend; px += PT) {
+    auto one = [&](const uint4& yv, const uint4& dv, const uint4& rv) {
       float v[CE], d[CE], r[CE];
-      Chunk<T>::unpack(*(const uint4*)(y + px * ysw + c), v);
-      Chunk<T>::unpack(*(const uint4*)(dz + px * dsw + c), d);
-      if (RES == 2) Chunk<T>::unpack(*(const uint4*)(res + px * rsw + c), r);
+      Chunk<T>::unpack(yv, v);
+      Chunk<T>::unpack(dv, d);
+      if (RES == 2) Chunk<T>::unpack(rv, r);
 #pragma unroll
       for (int j = 0; j < CE; ++j) {
         float g = d[j];
@@ -122,6 +141,20 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, cons
         s1[j] += g;
         s2[j] += g * (v[j] - mu[j]) * is[j];
       }
+    };
+    long px = pbeg + pt;
+    for (; px + PT < pend; px += 2 * PT) {  // two pixels in flight
+      const uint4 y0 = *(const uint4*)(y + px * ysw + c), y1 = *(const uint4*)(y + (px + PT) * ysw + c);
+      const uint4 d0 = *(const uint4*)(dz + px * dsw + c), d1 = *(const uint4*)(dz + (px + PT) * dsw + c);
+      uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+      if (RES == 2) { r0 = *(const uint4*)(res + px * rsw + c); r1 = *(const uint4*)(res + (px + PT) * rsw + c); }
+      one(y0, d0, r0);
+      one(y1, d1, r1);
+    }
+    if (px < pend) {
+      uint4 r0 = make_uint4(0, 0, 0, 0);
+      if (RES == 2) r0 = *(const uint4*)(res + px * rsw + c);
+      one(*(const uint4*)(y + px * ysw + c), *(const uint4*)(dz + px * dsw + c), r0);
     }
   }
 #pragma unroll
@@ -166,42 +199,68 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 // backward pass 2: dy = scale * (g - mean(g) - xhat * mean(g*xhat))      [TRAIN]
 //                  dy = scale * g                                         [eval / frozen stats]
 // optionally also emits g itself (gradient of a pre-activation residual).
+// Channel-stationary layout (as in pass 1): a block owns a 64-channel slab and a run of pixels; a thread keeps its chunk's six
+// per-channel constants in registers and walks the pixels, two in flight.  (The first version re-read the constants per element
+// and did a 64-bit division per chunk: 2.3 TB/s on the 839 MB head tensors against 4.2 TB/s for pass 1.)
 template <typename T, int ACT, int RES, bool TRAIN>
-__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
                                         const T* __restrict__ res, long rsw, const float* __restrict__ scale,
                                         const float* __restrict__ shift, const float* __restrict__ mean,
                                         const float* __restrict__ invstd, const float* __restrict__ mg,
                                         const float* __restrict__ mgx, T* __restrict__ dy, long dysw, T* __restrict__ dres,
-                                        long drsw, long P, int C) {
+                                        long drsw, long P, int C, int px_per_block) {
   constexpr int CE = TT<T>::CE;
-  const int cpr = C / CE;
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = P * cpr;
-  for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long px = idx / cpr;
-    int c = (int)(idx - px * cpr) * CE;
+  constexpr int CT = 64 / CE;    // chunk-threads per 64-channel slab
+  constexpr int PT = 256 / CT;   // pixel-threads
+  const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
+  const int c = blockIdx.y * 64 + ct * CE;
+  if (c >= C) return;
+  // dy = a * g + b * y + k   with  a = scale, b = -scale * invstd^2... kept explicit for exactness with the reference formula
+  float sc[CE], sf[CE], mu[CE], is[CE], m1[CE], m2[CE];
+#pragma unroll
+  for (int j = 0; j < CE; ++j) {
+    sc[j] = scale[c + j]; sf[j] = shift[c + j];
+    if (TRAIN) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; m1[j] = mg[c + j]; m2[j] = mgx[c + j]; }
+  }
+  const long pbeg = (long)blockIdx.x * px_per_block;
+  const long pend = pbeg + px_per_block < P ? pbeg + px_per_block : P;
+  auto one = [&](long px, const uint4& yv, const uint4& dv, const uint4& rv) {
     float v[CE], d[CE], r[CE], o[CE];
-    Chunk<T>::unpack(*(const uint4*)(y + px * ysw + c), v);
-    Chunk<T>::unpack(*(const uint4*)(dz + px * dsw + c), d);
-    if (RES == 2) Chunk<T>::unpack(*(const uint4*)(res + px * rsw + c), r);
+    Chunk<T>::unpack(yv, v);
+    Chunk<T>::unpack(dv, d);
+    if (RES == 2) Chunk<T>::unpack(rv, r);
 #pragma unroll
     for (int j = 0; j < CE; ++j) {
       float g = d[j];
       if (ACT) {
-        float u = v[j] * scale[c + j] + shift[c + j];
+        float u = v[j] * sc[j] + sf[j];
         if (RES == 2) u += r[j];
         g *= silu_grad_f(u);
       }
       d[j] = g;
       if (TRAIN) {
-        float xh = (v[j] - mean[c + j]) * invstd[c + j];
-        o[j] = scale[c + j] * (g - mg[c + j] - xh * mgx[c + j]);
+        float xh = (v[j] - mu[j]) * is[j];
+        o[j] = sc[j] * (g - m1[j] - xh * m2[j]);
       } else {
-        o[j] = scale[c + j] * g;
+        o[j] = sc[j] * g;
       }
     }
     *(uint4*)(dy + px * dysw + c) = Chunk<T>::pack(o);
     if (RES == 2 && dres) *(uint4*)(dres + px * drsw + c) = Chunk<T>::pack(d);
+  };
+  long px = pbeg + pt;
+  for (; px + PT < pend; px += 2 * PT) {
+    const uint4 y0 = *(const uint4*)(y + px * ysw + c), y1 = *(const uint4*)(y + (px + PT) * ysw + c);
+    const uint4 d0 = *(const uint4*)(dz + px * dsw + c), d1 = *(const uint4*)(dz + (px + PT) * dsw + c);
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    if (RES == 2) { r0 = *(const uint4*)(res + px * rsw + c); r1 = *(const uint4*)(res + (px + PT) * rsw + c); }
+    one(px, y0, d0, r0);
+    one(px + PT, y1, d1, r1);
+  }
+  if (px < pend) {
+    uint4 r0 = make_uint4(0, 0, 0, 0);
+    if (RES == 2) r0 = *(const uint4*)(res + px * rsw + c);
+    one(px, *(const uint4*)(y + px * ysw + c), *(const uint4*)(dz + px * dsw + c), r0);
   }
 }
 
@@ -225,6 +284,16 @@ __global__ void colsum_kernel(const T* __restrict__ x, long xsw, float* __restri
   }
 }
 
+// ~8 workgroups per CU as (pixel runs) x (64-channel slabs); a run is at least 64 pixels
+inline dim3 slab_grid(long P, int C, int* ppb) {
+  const int nslab = cdiv(C, 64);
+  long npx = 2048 / nslab;
+  if (npx < 1) npx = 1;
+  if (npx > (P + 63) / 64) npx = (P + 63) / 64;
+  *ppb = (int)((P + npx - 1) / npx);
+  return dim3((unsigned)npx, nslab);
+}
+
 inline int ew_grid(long total) {
   long b = (total + 255) / 256;
   return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
@@ -233,10 +302,11 @@ inline int ew_grid(long total) {
 template <typename T, int ACT>
 int launch_fwd(int res_mode, const void* y, long ysw, const float* scale, const float* shift, const void* res, long rsw,
                void* z, long zsw, long P, int C, hipStream_t st) {
-  dim3 g(ew_grid(P * (C / TT<T>::CE))), b(256);
-  if (res_mode == 0) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 0>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C);
-  else if (res_mode == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 1>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C);
-  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 2>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C);
+  int ppb;
+  dim3 g = slab_grid(P, C, &ppb), b(256);
+  if (res_mode == 0) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 0>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb);
+  else if (res_mode == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 1>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb);
+  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 2>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }
@@ -283,9 +353,13 @@ int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, co
              : launch_fwd<float, 0>(res_mode, y, ysw, scale, shift, res, rsw, z, zsw, P, C, st);
 }
 
-int y3d_bn_bwd_blocks(int64_t P) {
+int y3d_bn_bwd_blocks(int64_t P, int C) {
+  // pixel runs of >= 512 pixels; (runs) x (64-channel slabs) ~ 8 workgroups per CU, at most 2048 rows for the finalize pass
   long n = (P + 511) / 512;
-  return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+  long cap = 2048 / cdiv(C, 64);
+  if (cap < 64) cap = 64;
+  if (n > cap) n = cap;
+  return (int)(n < 1 ? 1 : n);
 }
 
 #define BWD_REDUCE(T, A, R)                                                                                                  \
@@ -297,7 +371,7 @@ int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz,
                           int res_mode, float* partials, int64_t P, int C, void* stream) {
   if (ew_check("bn_act_bwd_reduce y", dtype, y, ysw, C) || ew_check("bn_act_bwd_reduce dz", dtype, dz, dsw, C) ||
       ew_check("bn_act_bwd_reduce res", dtype, res, rsw, C)) return Y3D_ERR_INVALID;
-  int nblk = y3d_bn_bwd_blocks(P);
+  int nblk = y3d_bn_bwd_blocks(P, C);
   int ppb = (int)((P + nblk - 1) / nblk);
   dim3 grid(nblk, cdiv(C, 64));
   hipStream_t st = (hipStream_t)stream;
@@ -323,7 +397,7 @@ int y3d_bn_bwd_finalize(const float* partials, int nblk, int C, int64_t count, f
 
 #define BWD_APPLY(T, A, R, TR)                                                                                               \
   hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, A, R, TR>), grid, dim3(256), 0, st, (const T*)y, ysw, (const T*)dz, dsw,    \
-                     (const T*)res, rsw, scale, shift, mean, invstd, mean_g, mean_gx, (T*)dy, dysw, (T*)dres, drsw, (long)P, C)
+                     (const T*)res, rsw, scale, shift, mean, invstd, mean_g, mean_gx, (T*)dy, dysw, (T*)dres, drsw, (long)P, C, ppb)
 #define BWD_APPLY_T(T)                                                        \
   do {                                                                        \
     if (train) {                                                              \
@@ -343,7 +417,8 @@ int y3d_bn_act_bwd_apply(int dtype, const void* y, int64_t ysw, const void* dz, 
       ew_check("bn_act_bwd_apply dy", dtype, dy, dysw, C) || ew_check("bn_act_bwd_apply res", dtype, res, rsw, C) ||
       ew_check("bn_act_bwd_apply dres", dtype, dres, drsw, C)) return Y3D_ERR_INVALID;
   int r2 = res_mode == 2 ? 2 : 0;
-  dim3 grid(ew_grid(P * (C / (dtype == Y3D_BF16 ? 8 : 4))));
+  int ppb;
+  dim3 grid = slab_grid(P, C, &ppb);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == Y3D_BF16) BWD_APPLY_T(bf16_t); else BWD_APPLY_T(float);
   Y3D_LAUNCH_CHECK();
@@ -352,7 +427,7 @@ int y3d_bn_act_bwd_apply(int dtype, const void* y, int64_t ysw, const void* dz, 
 
 int y3d_colsum_partials(int dtype, const void* x, int64_t xsw, float* partials, int64_t P, int C, void* stream) {
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "colsum: bad dtype");
-  int nblk = y3d_bn_bwd_blocks(P);
+  int nblk = y3d_bn_bwd_blocks(P, C);
   int ppb = (int)((P + nblk - 1) / nblk);
   dim3 grid(nblk, cdiv(C, 64));
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)xsw, partials, (long)P, C, ppb);

@@ -229,7 +229,7 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
     esz = 2 if dtype == torch.bfloat16 else 4
     M = B * Ho * Wo
     dz = to_nhwc(dz, dtype, dense=True)
-    nb = L.bn_bwd_blocks(M)
+    nb = L.bn_bwd_blocks(M, Cout)
     part = _f32(nb * Cout * 2, dev)
     rptr = rr.data_ptr() if rr is not None else None
     rsw = rr.stride(3) if rr is not None else 0
