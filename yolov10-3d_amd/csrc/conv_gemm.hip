@@ -321,15 +321,18 @@ struct WgradP {
   int Ktot, M, nsplit, chunk_px;  // chunk_px: pixels per split (multiple of BPK)
 };
 
-template <typename T> struct TFrag;
-template <> struct TFrag<bf16_t> {
-  // LDS tile [pixel][128 elements] (256-byte rows); one MFMA k-sub-step = 32 pixels.
-  // A/B fragment: two transposed 4x16 block reads.  The pixel <-> MFMA-k assignment is a free permutation of the reduction
-  // index (A and B use the same one): k = 8g+j  <->  pixel row k0 + 16*(j>>2) + 4g + (j&3), so that the two 16-lane groups of a
-  // 32-lane half read 8 CONSECUTIVE rows per instruction, which the padded pitch spreads over all 64 banks.
+// LDS operand tiles are [pixel][W channels] with a padded row pitch; fragments are read transposed (the reduction runs over
+// pixels).  W = 128 / 64 / 32 channels: narrow layers (the stem, 32/64-channel 1x1 convs) get narrow tiles, so that their
+// workgroups carry only useful bytes and several of them fit a CU (their pixel loop is latency-bound).
+template <typename T, int W> struct TFrag;
+template <int W> struct TFrag<bf16_t, W> {
+  // one MFMA k-sub-step = 32 pixels.  A/B fragment: two transposed 4x16 block reads.  The pixel <-> MFMA-k assignment is a free
+  // permutation of the reduction index (A and B use the same one): k = 8g+j  <->  pixel row k0 + 16*(j>>2) + 4g + (j&3), so
+  // that the two 16-lane groups of a 32-lane half read 8 CONSECUTIVE rows per instruction; the pitch (in dwords) is 8 * odd, so
+  // those 8 rows x 32 bytes cover all 64 banks once.
   typedef bf16x8_t type;
   static constexpr int KSUB_PX = 32;
-  static constexpr int PITCH = 256 + 32;  // +32 B per pixel row: the 8 rows a 32-lane half touches in one transposed read cover all 64 banks once
+  static constexpr int PITCH = W * 2 + 32;  // 288 / 160 / 96 bytes
   __device__ static __forceinline__ type load(const char* tile, int i0, int k0, int lane) {
     int grp = lane >> 4, li = lane & 15;
     int q = li >> 2, pp = li & 3;
@@ -344,11 +347,11 @@ template <> struct TFrag<bf16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
-template <> struct TFrag<float> {
-  // LDS tile [pixel][128 floats] (512-byte rows); one MFMA k-sub-step = 4 pixels.
+template <int W> struct TFrag<float, W> {
+  // one MFMA k-sub-step = 4 pixels; row r+1 lands 16 banks after row r: the 2 rows x 16 floats of a half are conflict-free
   typedef float type;
   static constexpr int KSUB_PX = 4;
-  static constexpr int PITCH = 512 + 64;  // row r+1 lands 16 banks after row r: the 2 rows x 16 floats of a half are conflict-free
+  static constexpr int PITCH = W * 4 + 64;  // 576 / 320 / 192 bytes
   __device__ static __forceinline__ type load(const char* tile, int i0, int k0, int lane) {
     return *(const float*)(tile + (k0 + (lane >> 4)) * PITCH + (i0 + (lane & 15)) * 4);
   }
@@ -357,25 +360,26 @@ template <> struct TFrag<float> {
   }
 };
 
-// 128 (co) x 128 (k index) output tile, reduction over pixels in steps of BPK; 4 waves as 2x2 (64x64 each).
-template <typename T>
+// WD (co) x WX (k index) output tile, reduction over pixels in steps of BPK; 4 waves as 2x2 quadrants.
+template <typename T, int WD, int WX>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int CE = TT<T>::CE;
-  constexpr int BPK = TT<T>::BKE;            // 64 pixels (bf16) / 32 pixels (fp32) per step: 16 KB per operand tile
-  constexpr int ROWD = 128 * sizeof(T);      // data bytes per pixel row
-  constexpr int ROWB = TFrag<T>::PITCH;      // LDS row pitch (padded against bank conflicts)
-  constexpr int CPR = ROWD / 16;             // chunks per row (16 / 32)
-  constexpr int NCH = BPK * CPR / 256;       // chunks per thread per operand (4)
+  constexpr int BPK = TT<T>::BKE;            // 64 pixels (bf16) / 32 pixels (fp32) per step
+  constexpr int PD = TFrag<T, WD>::PITCH, PX = TFrag<T, WX>::PITCH;  // LDS row pitches (padded against bank conflicts)
+  constexpr int CPD = WD * sizeof(T) / 16, CPX = WX * sizeof(T) / 16;  // chunks per row
+  constexpr int ND = BPK * CPD / 256 > 0 ? BPK * CPD / 256 : 1;        // chunks per thread per step (4 / 2 / 1)
+  constexpr int NX = BPK * CPX / 256 > 0 ? BPK * CPX / 256 : 1;
+  constexpr int TA = WD / 32, TB = WX / 32;  // 16 x 16 sub-tiles per wave quadrant
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sD = smem;                 // [2][BPK][ROWB]  dy tile  (pixel x co)
-  char* sX = smem + 2 * BPK * ROWB;  // [2][BPK][ROWB]  x tile   (pixel x k)
+  char* sD = smem;                   // [2][BPK][PD]  dy tile  (pixel x co)
+  char* sX = smem + 2 * BPK * PD;    // [2][BPK][PX]  x tile   (pixel x k)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
   const int g = blockIdx.z % p.G;
   const int split = blockIdx.z / p.G;
-  const int j0 = blockIdx.x * 128;  // k-index tile origin
-  const int i0 = blockIdx.y * 128;  // co tile origin
+  const int j0 = blockIdx.x * WX;  // k-index tile origin
+  const int i0 = blockIdx.y * WD;  // co tile origin
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ D = (const T*)p.dy;
 
@@ -383,25 +387,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int mend = min(p.M, mbeg + p.chunk_px);
   const int nsteps = (mend - mbeg + BPK - 1) / BPK;
 
-  // chunk q = tid + 256*i -> row q / CPR, column chunk q % CPR.  CPR divides 256 so the column is fixed per thread.
-  const int cc = tid % CPR;
-  const int rr0 = tid / CPR;
-  constexpr int RSTEP = 256 / CPR;
+  // chunk q = tid + 256*i of an operand tile -> row q / CPR, column chunk q % CPR (CPR divides 256: the column is fixed per thread;
+  // fp32 tiles of 32 pixels x 32 channels have fewer chunks than threads: the upper threads idle for that operand)
+  const int ccd = tid % CPD, rd0 = tid / CPD;
+  const int ccx = tid % CPX, rx0 = tid / CPX;
+  constexpr int RSD = 256 / CPD, RSX = 256 / CPX;
+  const bool tdv = BPK * CPD >= 256 || tid < BPK * CPD, txv = BPK * CPX >= 256 || tid < BPK * CPX;
   // x-tile column: k index -> (tap, ci) fixed for the whole kernel
-  const int kx = j0 + cc * CE;
-  const bool kx_ok = kx < p.Ktot;
+  const int kx = j0 + ccx * CE;
+  const bool kx_ok = txv && kx < p.Ktot;
   int tap = 0, ci = 0, tr = 0, tq = 0;
   if (kx_ok) { tap = kx / p.Cg; ci = kx - tap * p.Cg; tr = tap / p.kw; tq = tap - tr * p.kw; }
-  const int cd = i0 + cc * CE;  // dy-tile column: output channel
-  const bool cd_ok = cd < p.Cn;
+  const int cd = i0 + ccd * CE;  // dy-tile column: output channel
+  const bool cd_ok = tdv && cd < p.Cn;
   const int HW = p.Ho * p.Wo;
 
-  uint4 rd[NCH], rx[NCH];
-  // per-row pixel coordinates, decoded once and advanced by BPK pixels per step (no divisions in the loop)
-  int rb_[NCH], rh_[NCH], rw_[NCH];
+  uint4 rd[ND], rx[NX];
+  // per-row pixel coordinates of the x rows, decoded once and advanced by BPK pixels per step (no divisions in the loop)
+  int rb_[NX], rh_[NX], rw_[NX];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    int m = mbeg + rr0 + RSTEP * i;
+  for (int i = 0; i < NX; ++i) {
+    int m = mbeg + rx0 + RSX * i;
     int b = m / HW;
     int rem = m - b * HW;
     rb_[i] = b;
@@ -412,18 +418,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const T* xcol = X + (long)g * p.Cg + ci + (long)(tr - p.pad) * p.xsh + (long)(tq - p.pad) * p.xsw;
   auto gload = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      int m = mbeg + st * BPK + rr0 + RSTEP * i;
-      uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-      if (m < mend) {
-        if (cd_ok) vd = *(const uint4*)(dcol + (long)m * p.dsw);
-        if (kx_ok) {
-          int hh = rh_[i] * p.stride - p.pad + tr, ww = rw_[i] * p.stride - p.pad + tq;
-          if (hh >= 0 && ww >= 0 && hh < p.H && ww < p.W)
-            vx = *(const uint4*)(xcol + (long)rb_[i] * p.xsb + (long)(rh_[i] * p.stride) * p.xsh + (long)(rw_[i] * p.stride) * p.xsw);
-        }
-      }
+    for (int i = 0; i < ND; ++i) {
+      int m = mbeg + st * BPK + rd0 + RSD * i;
+      uint4 vd = make_uint4(0, 0, 0, 0);
+      if (m < mend && cd_ok) vd = *(const uint4*)(dcol + (long)m * p.dsw);
       rd[i] = vd;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      int m = mbeg + st * BPK + rx0 + RSX * i;
+      uint4 vx = make_uint4(0, 0, 0, 0);
+      if (m < mend && kx_ok) {
+        int hh = rh_[i] * p.stride - p.pad + tr, ww = rw_[i] * p.stride - p.pad + tq;
+        if (hh >= 0 && ww >= 0 && hh < p.H && ww < p.W)
+          vx = *(const uint4*)(xcol + (long)rb_[i] * p.xsb + (long)(rh_[i] * p.stride) * p.xsh + (long)(rw_[i] * p.stride) * p.xsw);
+      }
       rx[i] = vx;
       rw_[i] += BPK;
       while (rw_[i] >= p.Wo) { rw_[i] -= p.Wo; ++rh_[i]; }
@@ -431,19 +440,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
   };
   auto lstore = [&](int buf) {
+    if (tdv) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      int r = rr0 + RSTEP * i;
-      *(uint4*)(sD + buf * BPK * ROWB + r * ROWB + cc * 16) = rd[i];
-      *(uint4*)(sX + buf * BPK * ROWB + r * ROWB + cc * 16) = rx[i];
+      for (int i = 0; i < ND; ++i) *(uint4*)(sD + buf * BPK * PD + (rd0 + RSD * i) * PD + ccd * 16) = rd[i];
+    }
+    if (txv) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) *(uint4*)(sX + buf * BPK * PX + (rx0 + RSX * i) * PX + ccx * 16) = rx[i];
     }
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[TA][TB];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < TB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   if (nsteps > 0) {
     gload(0);
@@ -453,19 +464,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1;
     if (st + 1 < nsteps) gload(st + 1);
-    const char* tD = sD + cur * BPK * ROWB;
-    const char* tX = sX + cur * BPK * ROWB;
+    const char* tD = sD + cur * BPK * PD;
+    const char* tX = sX + cur * BPK * PX;
 #pragma unroll
-    for (int k0 = 0; k0 < BPK; k0 += TFrag<T>::KSUB_PX) {
-      typename TFrag<T>::type fa[4], fb[4];
+    for (int k0 = 0; k0 < BPK; k0 += TFrag<T, WD>::KSUB_PX) {
+      typename TFrag<T, WD>::type fa[TA], fb[TB];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) fa[a] = TFrag<T>::load(tD, wi * 64 + a * 16, k0, lane);
+      for (int a = 0; a < TA; ++a) fa[a] = TFrag<T, WD>::load(tD, wi * (WD / 2) + a * 16, k0, lane);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) fb[b] = TFrag<T>::load(tX, wj * 64 + b * 16, k0, lane);
+      for (int b = 0; b < TB; ++b) fb[b] = TFrag<T, WX>::load(tX, wj * (WX / 2) + b * 16, k0, lane);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = TFrag<T>::mma(fa[a], fb[b], acc[a][b]);
+        for (int b = 0; b < TB; ++b) acc[a][b] = TFrag<T, WD>::mma(fa[a], fb[b], acc[a][b]);
     }
     if (st + 1 < nsteps) lstore(cur ^ 1);
     __syncthreads();
@@ -473,32 +484,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   // D[i][j]: row i = co = (lane>>4)*4 + reg, col j = k index = lane&15
   float* slab = p.slab + ((long)split * p.G * p.Cn + (long)g * p.Cn) * p.Ktot;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int k = j0 + wj * 64 + b * 16 + (lane & 15);
+    for (int b = 0; b < TB; ++b) {
+      int k = j0 + wj * (WX / 2) + b * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int co = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
+        int co = i0 + wi * (WD / 2) + a * 16 + (lane >> 4) * 4 + r;
         if (co < p.Cn && k < p.Ktot) slab[(long)co * p.Ktot + k] = acc[a][b][r];
       }
     }
 }
 
-// slab[split][co][tap][ci]  ->  grad OIHW [co][ci][tap]  (accumulate optional)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int Ctot,
-                                    int taps, int Cg, int Cg_real, int accumulate) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// slab[split][co][tap][ci]  ->  grad OIHW [co][ci][tap]  (accumulate optional).  SL split-lanes per element: a narrow layer has
+// few elements and many splits, so the split loop is shared by SL threads and folded through LDS.
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int Ctot,
+                                                           int taps, int Cg, int Cg_real, int accumulate) {
+  constexpr int EPB = 256 / SL;  // elements per block
+  __shared__ float sh[SL][EPB];
+  const int e = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+  long idx = (long)blockIdx.x * EPB + e;
   long n = (long)Ctot * taps * Cg;
+  float s = 0.f;
+  if (idx < n)
+    for (int k = sl; k < nsplit; k += SL) s += slab[(long)k * n + idx];
+  if (SL > 1) {
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl != 0) return;
+#pragma unroll
+    for (int j = 1; j < SL; ++j) s += sh[j][e];
+  }
   if (idx >= n) return;
   int ci = idx % Cg;
   int tap = (idx / Cg) % taps;
   int co = idx / ((long)Cg * taps);
-  if (ci >= Cg_real) return;  // channel padding (stem)
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + idx];
+  if (ci >= Cg_real) return;  // channel padding
   long o = ((long)co * Cg_real + ci) * taps + tap;
   grad[o] = accumulate ? grad[o] + s : s;
+}
+
+inline void launch_wgrad_reduce(const float* slab, float* grad, int nsplit, int Ctot, int taps, int Cg, int Cg_real, int accumulate, hipStream_t st) {
+  long n = (long)Ctot * taps * Cg;
+  if (n <= 65536 && nsplit >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 16)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
 }
 
 // OIHW fp32 -> packed [Cout][taps][Cg_pad] (forward) in T, row pitch Kpad
@@ -717,15 +747,24 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   return launch_conv<float, true>(p, (hipStream_t)stream);
 }
 
+static inline int wgrad_tile_w(int n) { return n <= 32 ? 32 : (n <= 64 ? 64 : 128); }  // operand tile width of the generic wgrad kernel
+
 int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_g, int groups, int kh, int kw) {
   int bpk = dtype == Y3D_BF16 ? 64 : 32;
   long M = (long)B * Ho * Wo;
-  long tiles = (long)cdiv(kh * kw * Cin_g, 128) * cdiv(Cout / groups, 128) * groups;
-  long want = cdiv(512, tiles);  // ~2 workgroups per CU; every extra split is one more fp32 slab to write and re-read
-  long maxs = cdiv(M, bpk);
+  long tiles = (long)cdiv(kh * kw * Cin_g, wgrad_tile_w(kh * kw * Cin_g)) * cdiv(Cout / groups, wgrad_tile_w(Cout / groups)) * groups;
+  // every extra split is one more fp32 slab to write and re-read, so: ~2 workgroups per CU when the slab is large, ~4 when it is
+  // small (the pixel loop of a narrow layer is latency-bound: 128 splits left half of the CUs idle on the stem), at least
+  // 4 K-steps per split, at most 32 MB of slabs
+  long slab = (long)Cout * kh * kw * Cin_g * 4;
+  long want = cdiv(slab <= (1 << 20) ? 1024 : 512, tiles);
+  long maxs = cdiv(M, 4 * bpk);
   if (want > maxs) want = maxs;
+  long cap = (32L << 20) / slab;
+  if (cap < 128) cap = 128;
+  if (want > cap) want = cap;
+  if (want > 1024) want = 1024;
   if (want < 1) want = 1;
-  if (want > 128) want = 128;
   return (int)want;
 }
 
@@ -757,19 +796,29 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
       int rc = y3d_conv3x3_wgrad_tile_launch(th, x, xsb, xsh, xsw, dy, dsw, B, H, W, p.Cg, p.Cn, groups, slab, nsplit, stream);
       if (rc) return rc;
       long n2 = (long)Cout * kh * kw * p.Cg;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, st, slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, p.Cg, accumulate);
+      (void)n2;
+      launch_wgrad_reduce(slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, p.Cg, accumulate, st);
       Y3D_LAUNCH_CHECK();
       return Y3D_OK;
     }
   }
-  dim3 grid(cdiv(p.Ktot, 128), cdiv(p.Cn, 128), groups * nsplit);
-  size_t sm = dtype == Y3D_BF16 ? 4 * 64 * (256 + 32) : 4 * 32 * (512 + 64);
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), sm, st, p);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), sm, st, p);
+  const int wd = wgrad_tile_w(p.Cn), wx = wgrad_tile_w(p.Ktot);
+  dim3 grid(cdiv(p.Ktot, wx), cdiv(p.Cn, wd), groups * nsplit);
+#define Y3D_WGRAD(T, WD, WX)                                                                                         \
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, WD, WX>), grid, dim3(256),                                                  \
+                     2 * TT<T>::BKE * (size_t)(TFrag<T, WD>::PITCH + TFrag<T, WX>::PITCH), st, p)
+#define Y3D_WGRAD_T(T)                                                                                               \
+  do {                                                                                                               \
+    if (wd == 128) { if (wx == 128) Y3D_WGRAD(T, 128, 128); else if (wx == 64) Y3D_WGRAD(T, 128, 64); else Y3D_WGRAD(T, 128, 32); } \
+    else if (wd == 64) { if (wx == 128) Y3D_WGRAD(T, 64, 128); else if (wx == 64) Y3D_WGRAD(T, 64, 64); else Y3D_WGRAD(T, 64, 32); } \
+    else { if (wx == 128) Y3D_WGRAD(T, 32, 128); else if (wx == 64) Y3D_WGRAD(T, 32, 64); else Y3D_WGRAD(T, 32, 32); }    \
+  } while (0)
+  if (dtype == Y3D_BF16) Y3D_WGRAD_T(bf16_t); else Y3D_WGRAD_T(float);
+#undef Y3D_WGRAD_T
+#undef Y3D_WGRAD
   Y3D_LAUNCH_CHECK();
-  long n = (long)Cout * kh * kw * p.Cg;
   int cg_real = groups == 1 ? Cin_real : p.Cg;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, cg_real, accumulate);
+  launch_wgrad_reduce(slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, cg_real, accumulate, st);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

@@ -145,6 +145,15 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     Ho = (H + 2 * p - k) // s + 1
     Wo = (W + 2 * p - k) // s + 1
     M = B * Ho * Wo
+    if Cin == 3 and k == 3 and s == 2 and p == 1 and g == 1 and not x.requires_grad:
+        # the stem: im2col the image once (27 window values + 5 zeros per output pixel) and run a dense 1x1 conv with K = 32;
+        # as a 9-tap conv over an 8-channel-padded image the MFMA tiles were 86 % padding.  dW is mapped back in _cba_backward.
+        xcol = nhwc_empty(B, 32, Ho, Wo, dtype, dev)
+        L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
+        wcol = torch.zeros(Cout, 32, dtype=torch.float32, device=dev)
+        wcol[:, :27] = w32.detach().permute(0, 2, 3, 1).reshape(Cout, 27)  # column (r*3+q)*3+ci
+        z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache)
+        return z, (cfg + ("stem",) if cfg is not None else None), saved
     dw = g > 1 and g == Cin and g == Cout
     # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
     Cin_k = Cin
@@ -220,7 +229,8 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
     (the one-to-one head sees a detached input, reference head.py:820)."""
     L = lib()
     xin, w32, y, stats, rr = saved
-    B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg
+    stem = len(cfg) > 17
+    B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg[:17]
     if not training:
         raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
     dt = code(dtype)
@@ -277,6 +287,9 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
         _timed(("conv_wgrad", dt, B, H, W, Cin_k, Cout, k, s, g),
                lambda: L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, Cin, dy.data_ptr(), Cout, Ho, Wo, Cout, g, k, k,
                                            s, p, slab.data_ptr(), ns, dW.data_ptr(), 0, st))
+    if stem:  # [Cout][(r*3+q)*3+ci | 5 zeros] -> OIHW (Cout, 3, 3, 3); the image itself gets no gradient
+        dW = dW.reshape(Cout, 32)[:, :27].reshape(Cout, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        dx = None
     return dx, dW, dgb[0], dgb[1], dres
 
 
