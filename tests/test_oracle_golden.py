@@ -261,3 +261,42 @@ def test_e2e_tiny2d():
         out = RS.forward(spec, st2, g["img"], False)
     close(out["one2one"][0], g["y_eval_o2o"], rtol=1e-3, atol=1e-3)
     close(out["one2many"][0], g["y_eval_o2m"], rtol=1e-3, atol=1e-3)
+
+
+def test_e2e_n2d_320_baseline_config0():
+    """BASELINE.json configs[0]: the shipped YOLOv10-N 2D yaml (nc=80), 320x320, batch 2 — one training step + eval + postprocess of
+    the reference's CPU path (oracle/make_golden_configs.py) against the restatement"""
+    g = load_golden("e2e_n2d_320")
+    import yaml
+    with open(os.path.join(ROOT, "yolov10-3d_amd", "cfg", "models", "v10", "yolov10n.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["scale"] = "n"
+    spec = RS.build_spec(cfg)
+    strides = RS.model_strides(spec)
+    assert [float(s) for s in strides] == [float(s) for s in g["strides"]]
+    st = {k: v.clone() for k, v in g["state"].items()}
+    assert set(RS.init_state(spec).keys()) == set(st)
+    for k, v in st.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    img = g["img8"].float() / 255
+    preds = RS.forward(spec, st, img, True)
+    loss, items, _ = RS.loss2d(preds, g["batch"], strides, 80)
+    close(loss, g["loss"].squeeze(), rtol=2e-5, atol=1e-3)
+    close(items, g["items"], rtol=1e-4, atol=1e-5)
+    loss.backward()
+    for k, gv in g["grads"].items():
+        close_rel(st[k].grad, gv, 5e-4)
+    big = max(float(v) for v in g["grad_norms"].values())
+    for k, nv in g["grad_norms"].items():  # every parameter's gradient norm (exact-zero-in-theory ones on the scale of the largest)
+        assert abs(float(st[k].grad.norm()) - float(nv)) <= 1e-3 * max(float(nv), 1e-3 * big), k
+    st2 = {k: v.clone() for k, v in g["state"].items()}
+    st2.update({k: v.clone() for k, v in g["state_after"].items()})
+    with torch.no_grad():
+        out = RS.forward(spec, st2, img, False)
+    close(out["one2one"][0], g["y_eval_o2o"], rtol=1e-3, atol=1e-3)
+    close(out["one2many"][0], g["y_eval_o2m"], rtol=1e-3, atol=1e-3)
+    bx, sc, lab = RS.postprocess2d(g["y_eval_o2o"].permute(0, 2, 1), 300, 80)
+    assert torch.equal(lab.long(), g["post_labels"].long())
+    close(sc, g["post_scores"], rtol=1e-6, atol=1e-7)
+    close(bx, g["post_boxes"], rtol=1e-6, atol=1e-5)
