@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
   constexpr int CE = TT<T>::CE;
   constexpr int CT = 64 / CE;
   constexpr int PT = 256 / CT;
-  constexpr int OG = 4;
+  constexpr int OG = 8;  // outputs per pass over the pixel range (the 24-output heading branch: 3 passes)
   __shared__ float sh[PT][64];
   const int br = blockIdx.z, Cin = g.cin, Cout = g.cout[br];
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
@@ -120,18 +120,29 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
       for (int j = 0; j < CE; ++j) acc[o][j] = 0.f;
     }
     if (c < Cin) {
-      for (long px = pbeg + pt; px < pend; px += PT) {
+      const int no = Cout - o0 < OG ? Cout - o0 : OG;
+      auto one = [&](const uint4& xv, const T* drow) {
         float v[CE];
-        Chunk<T>::unpack(*(const uint4*)(xp + px * xsw + c), v);
+        Chunk<T>::unpack(xv, v);
 #pragma unroll
         for (int o = 0; o < OG; ++o)
-          if (o0 + o < Cout) {
-            float d = TT<T>::ld(dp + px * dsw + o0 + o);
+          if (o < no) {
+            float d = TT<T>::ld(drow + o);
             bacc[o] += d;
 #pragma unroll
             for (int j = 0; j < CE; ++j) acc[o][j] += d * v[j];
           }
+      };
+      long px = pbeg + pt;
+      for (; px + 3 * PT < pend; px += 4 * PT) {  // four pixels in flight: the loop is latency-bound otherwise (1.2 TB/s)
+        const uint4 x0 = *(const uint4*)(xp + px * xsw + c), x1 = *(const uint4*)(xp + (px + PT) * xsw + c);
+        const uint4 x2 = *(const uint4*)(xp + (px + 2 * PT) * xsw + c), x3 = *(const uint4*)(xp + (px + 3 * PT) * xsw + c);
+        one(x0, dp + px * dsw + o0);
+        one(x1, dp + (px + PT) * dsw + o0);
+        one(x2, dp + (px + 2 * PT) * dsw + o0);
+        one(x3, dp + (px + 3 * PT) * dsw + o0);
       }
+      for (; px < pend; px += PT) one(*(const uint4*)(xp + px * xsw + c), dp + px * dsw + o0);
     }
 #pragma unroll
     for (int o = 0; o < OG; ++o) {
