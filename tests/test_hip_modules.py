@@ -544,6 +544,37 @@ def test_attention_mfma_vs_valu(shape):
     check(res[1], ref, 2e-2, "attention MFMA vs fp32 math")
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 20, 2), (1, 7, 11, 1), (1, 40, 40, 4), (3, 20, 20, 2)])
+def test_attention_backward_mfma_vs_valu_and_autograd(shape):
+    """bf16 PSA attention backward: the MFMA kernels (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS) vs the fp32-VALU kernels and vs
+    torch autograd on plain fp32 math; the second output (v, consumed by the positional-encoding branch) feeds dv_extra"""
+    B, H, W, nh = shape
+    y3d.set_compute_dtype(torch.bfloat16)
+    L = y3d.lib()
+    torch.manual_seed(4)
+    kd, hd = 32, 64
+    x = torch.randn(B, nh * (2 * kd + hd), H, W, device=DEV)
+    r1 = torch.randn(B, nh * hd, H, W, device=DEV)
+    r2 = torch.randn(B, nh * hd, H, W, device=DEV)
+    res = {}
+    for enable in (1, 0):
+        old = L.set_tile_kernels(enable)
+        try:
+            qkv = y3d.ops.to_nhwc(x, torch.bfloat16).detach().requires_grad_(True)
+            o, v = y3d.ops.AttentionFn.apply(qkv, nh, kd, hd, kd ** -0.5)
+            ((o.float() * r1).sum() + (v.float() * r2).sum()).backward()
+            res[enable] = qkv.grad.float().clone()
+        finally:
+            L.set_tile_kernels(old)
+    check(res[1], res[0], 3e-2, "attention backward MFMA vs VALU")
+    xq = y3d.ops.to_nhwc(x, torch.bfloat16).float().detach().requires_grad_(True)
+    q, k, vv = xq.view(B, nh, 2 * kd + hd, H * W).split([kd, kd, hd], 2)
+    attn = ((q.transpose(-2, -1) @ k) * kd ** -0.5).softmax(-1)
+    ref = (vv @ attn.transpose(-2, -1)).reshape(B, nh * hd, H, W)
+    ((ref * r1).sum() + (vv.reshape(B, nh * hd, H, W) * r2).sum()).backward()
+    check(res[1], xq.grad, 3e-2, "attention backward MFMA vs autograd on fp32 math")
+
+
 def test_postprocess_hip_vs_reference_golden():
     from yolov10_3d_amd.loss import v10_3Dpostprocess, v10postprocess
     g = load_golden("post3d")

@@ -307,6 +307,203 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// MFMA backward (bf16, kd = 32, hd = 64), same register choreography as the forward:
+//   attn_bwd_q_mfma : one wave owns 16 queries (the lane's column).  Per 32 keys: S^T = K Q^T and dP^T = V dO^T tiles come out
+//     with four keys in the registers, dS^T = P^T o (dP^T - delta) becomes the B operand of dQ^T += K^T dS^T as it is; the K^T
+//     fragments come from a swizzled LDS image of K with the transposed read.  Also writes delta_i = dO_i . O_i.
+//   attn_bwd_kv_mfma: one wave owns 16 keys.  Per 32 queries: S = Q K^T and dP = dO V^T tiles with four queries in the registers;
+//     P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS, whose A fragments come from an LDS image
+//     [query][dO (64) | Q (32)] with the transposed read.
+// The reduction index <-> MFMA-k assignment is permuted as in the forward (k = 8g+j <-> row 32*ks + 16*(j>>2) + 4g + (j&3)).
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t ld8(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
+__device__ __forceinline__ bf16x8_t zero8() { return (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// transposed A fragment out of an LDS image with ROWB-byte rows whose 32-byte pieces are XOR-swizzled by the row:
+// element block [rows 32*ks + 16*hi + 4*grp + 0..3][columns col0 + 16-wide tile], lane li = 4*qq + pp4
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t frag_t(const char* img, int ks, int col0, int grp, int qq, int pp4) {
+  constexpr int SW = ROWB / 32 - 1;  // 32-byte pieces per row - 1 (3 for 128-byte rows, 7 for 256-byte rows)
+  s16x4_t v[2];
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+    const int P = ks * 32 + 16 * hi + 4 * grp + qq;
+    const int cch = (col0 >> 3) + (pp4 >> 1);  // 16-byte chunk of the row
+    const char* a = img + P * ROWB + ((cch ^ (((P >> (ROWB == 128 ? 1 : 0)) & SW) << 1)) << 4) + (pp4 & 1) * 8;
+    v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
+  }
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
+  typedef bf16_t T;
+  constexpr int KD = 32, HD = 64;
+  extern __shared__ __attribute__((aligned(16))) char sK[];  // [N32][128 B]: K in the first 64 bytes of a row (V-image geometry)
+  const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int hoff = h * (2 * KD + HD);
+  const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
+  const int n32 = (p.N + 31) & ~31;
+  for (int id = tid; id < n32 * 4; id += 256) {  // K image: 4 chunks of 16 B per key
+    const int P = id >> 2, s4 = id & 3;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (P < p.N) v = *(const uint4*)(base + (long)P * p.qsw + KD + s4 * 8);
+    *(uint4*)(sK + P * 128 + ((s4 ^ (((P >> 1) & 3) << 1)) << 4)) = v;
+  }
+  const bool qv = q0 + li < p.N;
+  const bf16x8_t fq = qv ? ld8(base + (long)(q0 + li) * p.qsw + 8 * grp) : zero8();
+  bf16x8_t fdo[2];
+  float delta = 0.f, lse = 0.f;
+  {
+    const T* dp = (const T*)p.dout + ((long)b * p.N + q0 + li) * p.dsw + h * HD;
+    const T* op = (const T*)p.out + ((long)b * p.N + q0 + li) * p.osw + h * HD;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      fdo[k2] = qv ? ld8(dp + 32 * k2 + 8 * grp) : zero8();
+      if (qv) {
+        const bf16x8_t fo = ld8(op + 32 * k2 + 8 * grp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)fdo[k2][j] * (float)fo[j];
+      }
+    }
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    if (qv) {
+      lse = p.lse[((long)b * p.nh + h) * p.N + q0 + li];
+      if (grp == 0) p.delta[((long)b * p.nh + h) * p.N + q0 + li] = delta;
+    }
+  }
+  __syncthreads();
+  f32x4_t dq[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+  for (int ks = 0; ks < n32 / 32; ++ks) {
+    float dsv[8];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      const int key = 32 * ks + 16 * hi + li;  // this lane's row of the A operands
+      const bool kv = key < p.N;
+      const T* kp = base + (long)key * p.qsw;
+      const bf16x8_t fk = kv ? ld8(kp + KD + 8 * grp) : zero8();
+      f32x4_t s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      f32x4_t dpt = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8_t fv = kv ? ld8(kp + 2 * KD + 32 * k2 + 8 * grp) : zero8();
+        dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fdo[k2], dpt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = qv && 32 * ks + 16 * hi + 4 * grp + r < p.N;
+        dsv[hi * 4 + r] = ok ? __expf(s[r] * p.scale - lse) * (dpt[r] - delta) : 0.f;
+      }
+    }
+    bf16x8_t fds;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fds[j] = (__bf16)dsv[j];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<128>(sK, ks, dt * 16, grp, qq, pp4), fds, dq[dt], 0, 0, 0);
+  }
+  if (qv) {
+    T* dst = (T*)p.dqkv + ((long)b * p.N + q0 + li) * p.gsw + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 u;
+      u.x = (unsigned)f2bf(dq[dt][0] * p.scale) | ((unsigned)f2bf(dq[dt][1] * p.scale) << 16);
+      u.y = (unsigned)f2bf(dq[dt][2] * p.scale) | ((unsigned)f2bf(dq[dt][3] * p.scale) << 16);
+      *(uint2*)(dst + dt * 16 + 4 * grp) = u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
+  typedef bf16_t T;
+  constexpr int KD = 32, HD = 64;
+  extern __shared__ __attribute__((aligned(16))) char sI[];  // [N32][256 B]: dO (128 B) | Q (64 B) | unused, 32-byte pieces swizzled by row & 7
+  const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int hoff = h * (2 * KD + HD);
+  const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
+  const T* dob = (const T*)p.dout + (long)b * p.N * p.dsw + h * HD;
+  const int n32 = (p.N + 31) & ~31;
+  for (int id = tid; id < n32 * 12; id += 256) {  // 12 chunks per query: 8 of dO, 4 of Q
+    const int P = id / 12, c = id - P * 12;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (P < p.N) v = c < 8 ? *(const uint4*)(dob + (long)P * p.dsw + c * 8) : *(const uint4*)(base + (long)P * p.qsw + (c - 8) * 8);
+    *(uint4*)(sI + P * 256 + ((c ^ ((P & 7) << 1)) << 4)) = v;
+  }
+  const bool kv = k0 + li < p.N;
+  const T* kp = base + (long)(k0 + li) * p.qsw;
+  const bf16x8_t fk = kv ? ld8(kp + KD + 8 * grp) : zero8();  // B operands: this lane's key
+  bf16x8_t fv[2];
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) fv[k2] = kv ? ld8(kp + 2 * KD + 32 * k2 + 8 * grp) : zero8();
+  const float* lsep = p.lse + ((long)b * p.nh + h) * p.N;
+  const float* delp = p.delta + ((long)b * p.nh + h) * p.N;
+  __syncthreads();
+  f32x4_t dv[4], dk[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  dk[0] = dk[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < n32 / 32; ++ks) {
+    float pv[8], dsv[8];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      const int qi = 32 * ks + 16 * hi + li;  // this lane's row of the A operands
+      const bool qv = qi < p.N;
+      const bf16x8_t fq = qv ? ld8(base + (long)qi * p.qsw + 8 * grp) : zero8();
+      f32x4_t s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fk, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      f32x4_t dpt = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8_t fd = qv ? ld8(dob + (long)qi * p.dsw + 32 * k2 + 8 * grp) : zero8();
+        dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fv[k2], dpt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qr = 32 * ks + 16 * hi + 4 * grp + r;  // the query of register r
+        const bool ok = kv && qr < p.N;
+        const float pe = ok ? __expf(s[r] * p.scale - lsep[qr]) : 0.f;
+        pv[hi * 4 + r] = pe;
+        dsv[hi * 4 + r] = ok ? pe * (dpt[r] - delp[qr]) : 0.f;
+      }
+    }
+    bf16x8_t fp, fds;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fp[j] = (__bf16)pv[j]; fds[j] = (__bf16)dsv[j]; }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<256>(sI, ks, ct * 16, grp, qq, pp4), fp, dv[ct], 0, 0, 0);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<256>(sI, ks, 64 + dt * 16, grp, qq, pp4), fds, dk[dt], 0, 0, 0);
+  }
+  if (kv) {
+    T* dst = (T*)p.dqkv + ((long)b * p.N + k0 + li) * p.gsw + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 u;
+      u.x = (unsigned)f2bf(dk[dt][0] * p.scale) | ((unsigned)f2bf(dk[dt][1] * p.scale) << 16);
+      u.y = (unsigned)f2bf(dk[dt][2] * p.scale) | ((unsigned)f2bf(dk[dt][3] * p.scale) << 16);
+      *(uint2*)(dst + KD + dt * 16 + 4 * grp) = u;
+    }
+    const T* ex = p.dv_extra ? (const T*)p.dv_extra + ((long)b * p.N + k0 + li) * p.esw + h * HD : nullptr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ex) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = bf2f(ex[ct * 16 + 4 * grp + r]);
+      }
+      uint2 u;
+      u.x = (unsigned)f2bf(dv[ct][0] + e[0]) | ((unsigned)f2bf(dv[ct][1] + e[1]) << 16);
+      u.y = (unsigned)f2bf(dv[ct][2] + e[2]) | ((unsigned)f2bf(dv[ct][3] + e[3]) << 16);
+      *(uint2*)(dst + 2 * KD + ct * 16 + 4 * grp) = u;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +544,20 @@ int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64
   AttnBP p{qkv, (long)qsw, out, (long)osw, dout, (long)dsw, dv_extra, (long)esw, dqkv, (long)gsw, lse, delta, B, N, nh, kd, hd, scale};
   dim3 grid(cdiv(N, 128), B * nh), block(128);
   hipStream_t st = (hipStream_t)stream;
+  const int n32 = (N + 31) & ~31;
+  if (dtype == Y3D_BF16 && kd == 32 && y3d_get_tile_kernels() && qsw % 8 == 0 && osw % 8 == 0 && dsw % 8 == 0 && gsw % 4 == 0 &&
+      (dv_extra == nullptr || esw % 1 == 0) && (size_t)n32 * 256 <= 160 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)n32 * 128, st, p);
+    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)n32 * 256, st, p);
+    Y3D_LAUNCH_CHECK();
+    return Y3D_OK;
+  }
 #define ATT_BWD(T, KD, HD)                                                              \
   hipLaunchKernelGGL((attn_bwd_q_kernel<T, KD, HD>), grid, block, 0, st, p);           \
   hipLaunchKernelGGL((attn_bwd_kv_kernel<T, KD, HD>), grid, block, 0, st, p)
