@@ -164,6 +164,14 @@ int y3d_proj_group_fwd(int dtype, int nb, int cin, const void* x, int64_t xsw, c
 int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t dsw, const int* xoff, const float* const* w,
                             const int* couts, void* dx, int64_t xsw, int64_t P, void* stream);
 int y3d_proj_group_blocks(int64_t P);
+/* the same projections fused with the BatchNorm (+SiLU) that precedes them: y_pre is the PRE-BatchNorm conv output; the activation
+ * act(y_pre * scale + shift) is formed on the fly (forward) / rebuilt (weight gradient) and never stored */
+int y3d_proj_group_fwd_bn(int dtype, int nb, int cin, const void* y_pre, int64_t xsw, const int* xoff, const float* const* w,
+                          const float* const* b, const int* couts, const float* scale, const float* shift, int act, void* out,
+                          int64_t ysw, int64_t P, void* stream);
+int y3d_proj_group_bwd_weight_bn(int dtype, int nb, int cin, const void* y_pre, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
+                                 const int* couts, const float* scale, const float* shift, int act, float* slab, float* bslab,
+                                 float* const* dw, float* const* db, int64_t P, void* stream);
 int y3d_proj_group_bwd_weight(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
                               const int* couts, float* slab, float* bslab, float* const* dw, float* const* db, int64_t P, void* stream);
 

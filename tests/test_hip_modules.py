@@ -134,6 +134,43 @@ def test_head3d_train_vs_reference_golden(tag, dtype, tol):
         check(named[k[len("model.0."):]].grad, gv, tol * 3, f"grad {k}")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+def test_head3d_bn_projection_fusion_matches_unfused(dtype, tol):
+    """64-channel branches: the fused node (grouped conv -> BatchNorm statistics -> projections applying BatchNorm + SiLU on the fly,
+    one reduce + one apply pass backward) against the unfused chain (bn_act_fwd, projections, projection data/weight gradients,
+    BatchNorm reduce/apply) on the same weights: head maps, input gradients and every parameter gradient"""
+    y3d.set_compute_dtype(dtype)
+    torch.manual_seed(7)
+    chan = {k + "_c": 64 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    hd = M.v10Detect3d(3, (32, 64), False, chan, False, False, False, False, 2, False, False, 3, 3)
+    hd.stride = torch.tensor([8.0, 16.0])
+    hd = hd.to(DEV).train()
+    with torch.no_grad():
+        for p_ in hd.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    xs0 = [torch.randn(3, 32, 24, 24, device=DEV), torch.randn(3, 64, 12, 12, device=DEV)]
+    rs = None
+    res = {}
+    for fused in (True, False):
+        hd.fuse_bn_proj = fused
+        hd.zero_grad(set_to_none=True)
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        out = hd(xs)
+        maps = out["one2many"] + out["one2one"]
+        if rs is None:
+            rs = [torch.randn_like(t.float()) for t in maps]
+        sum((t.float() * r).sum() for t, r in zip(maps, rs)).backward()
+        res[fused] = ([t.detach().float() for t in maps], [x.grad.float() for x in xs], {k: v.grad.float().clone() for k, v in hd.named_parameters() if v.grad is not None})
+    for a, b in zip(res[True][0], res[False][0]):
+        check(a, b, tol, "head map fused vs unfused")
+    for a, b in zip(res[True][1], res[False][1]):
+        check(a, b, tol * 3, "dx fused vs unfused")
+    assert set(res[True][2]) == set(res[False][2])
+    gf = 1e-3 * max(float(v.abs().max()) for v in res[False][2].values())
+    for k in res[False][2]:
+        check(res[True][2][k], res[False][2][k], tol * 3, f"grad {k}", gf)
+
+
 @pytest.mark.parametrize("tag", ["k33", "k31"])
 def test_head3d_eval_vs_reference_golden(tag):
     y3d.set_compute_dtype(torch.float32)

@@ -18,14 +18,25 @@ struct ProjG {
   int nb, cin;
 };
 
+// BN: the per-channel constants of the BatchNorm that precedes the projections, indexed by the channel of the STACKED tensor.
+// When given, x is the PRE-BatchNorm conv output and act(x * scale + shift) is formed on the fly: the activation tensor is
+// never materialised (forward) and neither is its gradient (backward): 6 passes over the 839 MB head tensors less per step.
+struct BNP {
+  const float* scale; const float* shift; const float* mean; const float* invstd; const float* mg; const float* mgx;
+  int act;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void projg_fwd_kernel(ProjG g, const T* __restrict__ x, long xsw, T* __restrict__ y, long ysw, long P) {
+__global__ __launch_bounds__(256) void projg_fwd_kernel(ProjG g, const T* __restrict__ x, long xsw, T* __restrict__ y, long ysw, long P, BNP bn) {
   constexpr int CE = TT<T>::CE;
   constexpr int CN = 24;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sw = (float*)smem;
+  float* sw = (float*)smem;             // [24][Cin]
+  float* sbn = sw + 24 * g.cin;         // [2][Cin] scale, shift of this branch's channels
   const int br = blockIdx.z, Cin = g.cin, Cout = g.cout[br];
   for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = g.w[br][i];
+  if (bn.scale)
+    for (int i = threadIdx.x; i < Cin; i += 256) { sbn[i] = bn.scale[g.xoff[br] + i]; sbn[Cin + i] = bn.shift[g.xoff[br] + i]; }
   __syncthreads();
   const int sub = threadIdx.x & 7;
   const int cpr = Cin / CE;
@@ -38,6 +49,13 @@ __global__ __launch_bounds__(256) void projg_fwd_kernel(ProjG g, const T* __rest
     for (int ch = sub; ch < cpr; ch += 8) {
       float v[CE];
       Chunk<T>::unpack(*(const uint4*)(xp + px * xsw + ch * CE), v);
+      if (bn.scale) {
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+          float u = v[j] * sbn[ch * CE + j] + sbn[Cin + ch * CE + j];
+          v[j] = TT<T>::rnd(bn.act ? silu_f(u) : u);  // rounded as the materialised activation tensor would be
+        }
+      }
 #pragma unroll
       for (int o = 0; o < CN; ++o)
         if (o < Cout) {
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256) void projg_bwd_data_kernel(ProjG g, const T* _
 template <typename T>
 __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T* __restrict__ x, long xsw, const T* __restrict__ dy, long dsw,
                                                                float* __restrict__ slab, float* __restrict__ bslab, long P, int ctot,
-                                                               int px_per_block) {
+                                                               int px_per_block, BNP bn) {
   constexpr int CE = TT<T>::CE;
   constexpr int CT = 64 / CE;
   constexpr int PT = 256 / CT;
@@ -121,9 +139,21 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
     }
     if (c < Cin) {
       const int no = Cout - o0 < OG ? Cout - o0 : OG;
+      float bsc[CE], bsh[CE];
+      if (bn.scale) {
+#pragma unroll
+        for (int j = 0; j < CE; ++j) { bsc[j] = bn.scale[g.xoff[br] + c + j]; bsh[j] = bn.shift[g.xoff[br] + c + j]; }
+      }
       auto one = [&](const uint4& xv, const T* drow) {
         float v[CE];
         Chunk<T>::unpack(xv, v);
+        if (bn.scale) {  // x is the pre-BatchNorm tensor: rebuild the activation the forward projected
+#pragma unroll
+          for (int j = 0; j < CE; ++j) {
+            const float u = v[j] * bsc[j] + bsh[j];
+            v[j] = TT<T>::rnd(bn.act ? silu_f(u) : u);
+          }
+        }
 #pragma unroll
         for (int o = 0; o < OG; ++o)
           if (o < no) {
@@ -211,19 +241,33 @@ int fill(ProjG& g, int nb, int cin, const float* const* w, const float* const* b
 
 extern "C" {
 
-int y3d_proj_group_fwd(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const float* const* w,
-                       const float* const* b, const int* couts, void* y, int64_t ysw, int64_t P, void* stream) {
+static int proj_group_fwd_impl(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const float* const* w,
+                               const float* const* b, const int* couts, void* y, int64_t ysw, int64_t P, BNP bn, void* stream) {
   ProjG g;
   int ctot = fill(g, nb, cin, w, b, nullptr, nullptr, xoff, couts);
   if (ctot < 0) return ctot;
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "proj_group_fwd: bad dtype");
   Y3D_CHECK(cin % (dtype == Y3D_BF16 ? 8 : 4) == 0 && ysw >= ctot, "proj_group_fwd: channel alignment");
   dim3 grid(cdiv(P, 32), 1, nb);
-  size_t sm = (size_t)24 * cin * 4;
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_fwd_kernel<bf16_t>, grid, dim3(256), sm, (hipStream_t)stream, g, (const bf16_t*)x, (long)xsw, (bf16_t*)y, (long)ysw, (long)P);
-  else hipLaunchKernelGGL(projg_fwd_kernel<float>, grid, dim3(256), sm, (hipStream_t)stream, g, (const float*)x, (long)xsw, (float*)y, (long)ysw, (long)P);
+  size_t sm = (size_t)26 * cin * 4;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_fwd_kernel<bf16_t>, grid, dim3(256), sm, (hipStream_t)stream, g, (const bf16_t*)x, (long)xsw, (bf16_t*)y, (long)ysw, (long)P, bn);
+  else hipLaunchKernelGGL(projg_fwd_kernel<float>, grid, dim3(256), sm, (hipStream_t)stream, g, (const float*)x, (long)xsw, (float*)y, (long)ysw, (long)P, bn);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
+}
+
+int y3d_proj_group_fwd(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const float* const* w,
+                       const float* const* b, const int* couts, void* y, int64_t ysw, int64_t P, void* stream) {
+  BNP bn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return proj_group_fwd_impl(dtype, nb, cin, x, xsw, xoff, w, b, couts, y, ysw, P, bn, stream);
+}
+
+int y3d_proj_group_fwd_bn(int dtype, int nb, int cin, const void* y_pre, int64_t xsw, const int* xoff, const float* const* w,
+                          const float* const* b, const int* couts, const float* scale, const float* shift, int act, void* out,
+                          int64_t ysw, int64_t P, void* stream) {
+  Y3D_CHECK(scale && shift, "proj_group_fwd_bn: scale / shift missing");
+  BNP bn{scale, shift, nullptr, nullptr, nullptr, nullptr, act};
+  return proj_group_fwd_impl(dtype, nb, cin, y_pre, xsw, xoff, w, b, couts, out, ysw, P, bn, stream);
 }
 
 int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t dsw, const int* xoff, const float* const* w,
@@ -246,8 +290,9 @@ int y3d_proj_group_blocks(int64_t P) {
 }
 
 /* slab: blocks * ctot * cin floats, bslab: blocks * ctot floats */
-int y3d_proj_group_bwd_weight(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
-                              const int* couts, float* slab, float* bslab, float* const* dw, float* const* db, int64_t P, void* stream) {
+static int proj_group_bwd_weight_impl(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
+                                      const int* couts, float* slab, float* bslab, float* const* dw, float* const* db, int64_t P, BNP bn,
+                                      void* stream) {
   ProjG g;
   const float* dummy[MAXB] = {nullptr};
   int ctot = fill(g, nb, cin, dummy, nullptr, dw, db, xoff, couts);
@@ -256,11 +301,25 @@ int y3d_proj_group_bwd_weight(int dtype, int nb, int cin, const void* x, int64_t
   int ppb = (int)((P + nblk - 1) / nblk);
   dim3 grid(nblk, cdiv(cin, 64), nb);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const bf16_t*)x, (long)xsw, (const bf16_t*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb);
-  else hipLaunchKernelGGL(projg_bwd_weight_kernel<float>, grid, dim3(256), 0, st, g, (const float*)x, (long)xsw, (const float*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const bf16_t*)x, (long)xsw, (const bf16_t*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb, bn);
+  else hipLaunchKernelGGL(projg_bwd_weight_kernel<float>, grid, dim3(256), 0, st, g, (const float*)x, (long)xsw, (const float*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb, bn);
   hipLaunchKernelGGL(projg_reduce_kernel, dim3(cdiv(24 * cin, 256), nb), dim3(256), 0, st, g, slab, bslab, nblk, ctot);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
+}
+
+int y3d_proj_group_bwd_weight(int dtype, int nb, int cin, const void* x, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
+                              const int* couts, float* slab, float* bslab, float* const* dw, float* const* db, int64_t P, void* stream) {
+  BNP bn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return proj_group_bwd_weight_impl(dtype, nb, cin, x, xsw, xoff, dy, dsw, couts, slab, bslab, dw, db, P, bn, stream);
+}
+
+int y3d_proj_group_bwd_weight_bn(int dtype, int nb, int cin, const void* y_pre, int64_t xsw, const int* xoff, const void* dy, int64_t dsw,
+                                 const int* couts, const float* scale, const float* shift, int act, float* slab, float* bslab,
+                                 float* const* dw, float* const* db, int64_t P, void* stream) {
+  Y3D_CHECK(scale && shift, "proj_group_bwd_weight_bn: scale / shift missing");
+  BNP bn{scale, shift, nullptr, nullptr, nullptr, nullptr, act};
+  return proj_group_bwd_weight_impl(dtype, nb, cin, y_pre, xsw, xoff, dy, dsw, couts, slab, bslab, dw, db, P, bn, stream);
 }
 
 }  // extern "C"

@@ -397,7 +397,11 @@ class v10Detect3d(nn.Module):
             half = sum(mids[:8])
             z1 = ops.FusedConvBNActFn.apply(x[i], s1, 1, (half, sum(mids)), *s1.params())
             offs = [sum(mids[:j]) for j in range(16)]
-            if s2 is not None:
+            if s2 is not None and mids[0] % 64 == 0 and getattr(self, "fuse_bn_proj", True):
+                # grouped conv + BatchNorm statistics + projections with BatchNorm/SiLU applied on the fly (no activation tensor)
+                out = ops.FusedConvBNProjFn.apply(z1, s2, len(branches), offs, mids, 16, *s2.params(), *[b[2].weight for b in branches],
+                                                  *[b[2].bias for b in branches])
+            elif s2 is not None:
                 z2 = ops.FusedConvBNActFn.apply(z1, s2, len(branches), None, *s2.params())
                 out = ops.HeadProjSlicesFn.apply(z2, offs, mids, 16, *[b[2].weight for b in branches], *[b[2].bias for b in branches])
             else:

@@ -131,7 +131,7 @@ def _timed(key, launch):
         launch()
 
 
-def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None):
+def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True):
     """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs."""
     L = lib()
     _require_gpu(x)
@@ -213,6 +213,9 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                       stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
     else:
         L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
+    if not bn_apply:  # the consumer applies BatchNorm + activation itself (FusedConvBNProjFn): hand back the pre-BN tensor
+        cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act))
+        return y, cfg, (xin, w32, y, stats, None)
     z = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
     rr = None
     if res_mode:
@@ -224,7 +227,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
 
 
-def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
+def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
     """-> dx, dW (fp32 OIHW), dgamma, dbeta, dres.  dx_range=(lo, hi): only output channels lo..hi feed dx
     (the one-to-one head sees a detached input, reference head.py:820)."""
     L = lib()
@@ -233,6 +236,8 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
     B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg[:17]
     if not training:
         raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
+    if pre is not None:  # (dy, dgb): the BatchNorm part was done by the caller (FusedConvBNProjFn)
+        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range)
     dt = code(dtype)
     st = stream()
     dev = dz.device
@@ -256,6 +261,20 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None):
                        dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
     if res_mode == 1:
         dres = dz
+    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range)
+
+
+def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
+    """data and weight gradients of the conv given dy (gradient wrt its pre-BatchNorm output)"""
+    L = lib()
+    xin, w32, y, stats, rr = saved
+    stem = len(cfg) > 17
+    B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg[:17]
+    dt = code(dtype)
+    st = stream()
+    dev = dy.device
+    esz = 2 if dtype == torch.bfloat16 else 4
+    M = B * Ho * Wo
     sb, sh, sw = s3(xin)
     dx = None
     dW = torch.empty_like(w32)
@@ -543,6 +562,83 @@ class HeadProjSlicesFn(torch.autograd.Function):
         L.proj_group_bwd_weight(dt, n, cin, x.data_ptr(), x.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, slab.data_ptr(),
                                 bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]), PV(*[t.data_ptr() for t in dbs]), P, st)
         return (dx, None, None, None, *dws, *dbs)
+
+
+class FusedConvBNProjFn(torch.autograd.Function):
+    """Second stacked head layer + the 16 projections of a level as ONE node: grouped conv -> BatchNorm statistics -> projections
+    that apply BatchNorm + SiLU on the fly (proj_group.hip).  The activation tensor is never materialised: the forward reads the
+    pre-BN tensor once instead of bn_act_fwd's read + write + the projections' read, and the projection weight gradient rebuilds
+    the activation from the pre-BN tensor.  (A fully fused backward - BatchNorm reduce / apply recomputing W^T dout per pixel on the
+    VALU - was measured slower than the three separate kernels and is not used.)  args: x, stack, groups, offsets, cins, n, *stack.params(), *proj_w, *proj_b"""
+
+    @staticmethod
+    def forward(ctx, x, stack, groups, offsets, cins, n, *params):
+        import ctypes
+        L = lib()
+        w, gm, bt, rm, rv = stack.tensors()
+        m = stack.convs[0]
+        npar = len(params) - 2 * n
+        ws, bs = params[npar:npar + n], params[npar + n:]
+        y, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum, bn_apply=False)
+        if m.training:
+            for c in stack.convs:
+                c._nbt_pending += 1
+        dtype = _COMPUTE_DTYPE
+        dt, st = code(dtype), stream()
+        B, Ct, H, W = y.shape
+        P = B * H * W
+        couts = [t.shape[0] for t in ws]
+        cin = cins[0]
+        assert all(c == cin for c in cins) and n <= 16 and n * cin == Ct and cin % 64 == 0
+        tot = sum(couts)
+        out = nhwc_empty(B, tot, H, W, dtype, y.device)
+        w32 = [t.detach().float().contiguous() for t in ws]
+        b32 = [t.detach().float().contiguous() for t in bs]
+        PV, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        stats = saved[3]
+        L.proj_group_fwd_bn(dt, n, cin, y.data_ptr(), y.stride(3), IA(*offsets), PV(*[t.data_ptr() for t in w32]), PV(*[t.data_ptr() for t in b32]),
+                            IA(*couts), stats[2].data_ptr(), stats[3].data_ptr(), int(m.has_act), out.data_ptr(), tot, P, st)
+        ctx.cfg, ctx.couts_stack, ctx.meta = cfg, stack.couts, (list(offsets), cin, n, couts, dtype, int(m.has_act))
+        ctx.nsaved = len(saved)
+        ctx.save_for_backward(*[t for t in saved if t is not None], *w32)
+        ctx.none_mask = [t is None for t in saved]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        L = lib()
+        offsets, cin, n, couts, dtype, act = ctx.meta
+        it = iter(ctx.saved_tensors)
+        saved = tuple(None if isnone else next(it) for isnone in ctx.none_mask)
+        ws = list(it)
+        xin, w32c, y, stats, _ = saved
+        dt, st = code(dtype), stream()
+        if not (dout.dtype == dtype and px_dense(dout)):
+            dout = _dense_any(dout, dtype)
+        B, Ct, H, W = y.shape
+        P = B * H * W
+        dev = y.device
+        tot = sum(couts)
+        PV, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        c_w, c_off, c_co = PV(*[t.data_ptr() for t in ws]), IA(*offsets), IA(*couts)
+        dz = nhwc_empty(B, Ct, H, W, dtype, dev)
+        L.proj_group_bwd_data(dt, n, cin, dout.data_ptr(), dout.stride(3), c_off, c_w, c_co, dz.data_ptr(), Ct, P, st)
+        dws = [torch.empty_like(t) for t in ws]
+        dbs = [_f32(co, dev) for co in couts]
+        nb = L.proj_group_blocks(P)
+        slab, bslab = _f32(nb * tot * cin, dev), _f32(nb * tot, dev)
+        L.proj_group_bwd_weight_bn(dt, n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, stats[2].data_ptr(),
+                                   stats[3].data_ptr(), act, slab.data_ptr(), bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]),
+                                   PV(*[t.data_ptr() for t in dbs]), P, st)
+        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None)
+        dWs, dgs, dbs_s, off = [], [], [], 0
+        for co in ctx.couts_stack:
+            dWs.append(dW[off:off + co])
+            dgs.append(dg[off:off + co])
+            dbs_s.append(db[off:off + co])
+            off += co
+        return (dx, None, None, None, None, None, *dWs, *dgs, *dbs_s, *dws, *dbs)
 
 
 def _dense_any(x, dtype):
