@@ -18,7 +18,9 @@ struct DwP {
   int px_per_block;
 };
 
-template <typename T, bool DGRAD>
+// K = 3 / 7: the filter rows are unrolled and a row's K loads are issued together (predicated, zero outside the map); with runtime
+// tap loops every load waited for the previous one (1 TB/s on the 3x3 layers).  K = 0: any filter size (runtime loops).
+template <typename T, bool DGRAD, int K>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
   constexpr int CE = TT<T>::CE;
   constexpr int CT = 64 / CE;
@@ -45,13 +47,40 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
     long pend = pbeg + p.px_per_block < p.M ? pbeg + p.px_per_block : p.M;
     const int HWq = p.Hq * p.Wq;
     for (long m = pbeg + pt; m < pend; m += PT) {
-      int b = (int)(m / HWq);
-      int rem = (int)(m - (long)b * HWq);
+      const int mi = (int)m;  // M < 2^31 (checked by the launcher)
+      int b = mi / HWq;
+      int rem = mi - b * HWq;
       int hq = rem / p.Wq, wq = rem - hq * p.Wq;
       float acc[CE];
 #pragma unroll
       for (int j = 0; j < CE; ++j) acc[j] = 0.f;
       const T* xb = X + (long)b * p.xsb + c;
+      if (K > 0) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          int hh;
+          bool okh;
+          if (DGRAD) { int t = hq + p.pad - r; hh = t / p.stride; okh = t >= 0 && hh * p.stride == t && hh < p.Hg; }
+          else { hh = hq * p.stride - p.pad + r; okh = hh >= 0 && hh < p.Hg; }
+          uint4 raw[K > 0 ? K : 1];
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            int ww;
+            bool okw;
+            if (DGRAD) { int t = wq + p.pad - q; ww = t / p.stride; okw = t >= 0 && ww * p.stride == t && ww < p.Wg; }
+            else { ww = wq * p.stride - p.pad + q; okw = ww >= 0 && ww < p.Wg; }
+            raw[q] = (okh && okw) ? *(const uint4*)(xb + (long)hh * p.xsh + (long)ww * p.xsw) : make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            float v[CE];
+            Chunk<T>::unpack(raw[q], v);
+            const float* wt = sw + (r * K + q) * 64 + ct * CE;
+#pragma unroll
+            for (int j = 0; j < CE; ++j) acc[j] += v[j] * wt[j];
+          }
+        }
+      } else
       for (int r = 0; r < p.kh; ++r) {
         int hh;
         bool okh;
@@ -199,17 +228,24 @@ int y3d_dw_pack_weight(const float* w_oihw, float* out, int C, int kh, int kw, v
   return Y3D_OK;
 }
 
+#define DW_LAUNCH_K(T, D, K) hipLaunchKernelGGL((dwconv_kernel<T, D, K>), grid, dim3(256), sm, st, p)
+#define DW_LAUNCH(T)                                                                                             \
+  do {                                                                                                           \
+    const int kk = (p.kh == p.kw && (p.kh == 3 || p.kh == 7)) ? p.kh : 0;                                        \
+    if (dgrad) { if (kk == 3) DW_LAUNCH_K(T, true, 3); else if (kk == 7) DW_LAUNCH_K(T, true, 7); else DW_LAUNCH_K(T, true, 0); }     \
+    else { if (kk == 3) DW_LAUNCH_K(T, false, 3); else if (kk == 7) DW_LAUNCH_K(T, false, 7); else DW_LAUNCH_K(T, false, 0); }        \
+  } while (0)
+
 static int dw_launch(int dtype, bool dgrad, const DwP& p, hipStream_t st) {
+  Y3D_CHECK(p.M < (1L << 31), "dwconv: more than 2^31 pixels");
   int ce = dtype == Y3D_BF16 ? 8 : 4;
   int pt = 256 / (64 / ce);
   size_t sm = (size_t)(p.kh * p.kw * 64 + pt * 64 * 2) * sizeof(float);
   dim3 grid(y3d_dw_blocks(p.M), cdiv(p.C, 64));  // blocks past the end write zero partials
   if (dtype == Y3D_BF16) {
-    if (dgrad) hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), grid, dim3(256), sm, st, p);
-    else hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), grid, dim3(256), sm, st, p);
+    DW_LAUNCH(bf16_t);
   } else {
-    if (dgrad) hipLaunchKernelGGL((dwconv_kernel<float, true>), grid, dim3(256), sm, st, p);
-    else hipLaunchKernelGGL((dwconv_kernel<float, false>), grid, dim3(256), sm, st, p);
+    DW_LAUNCH(float);
   }
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
