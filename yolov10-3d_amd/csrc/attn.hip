@@ -1,10 +1,9 @@
 // PSA attention core (reference nn/modules/block.py:785-797): per (image, head)
 //   attn = softmax_j( scale * q_i . k_j ),  out_i = sum_j attn_ij v_j
 // on the NHWC qkv tensor whose per-head channel block is [q(kd) | k(kd) | v(hd)].
-// Flash-style single pass (online softmax, no N x N matrix in memory), fp32 math, one query (or key)
-// per lane with the other operand streamed through LDS in 64-row tiles.  N is tiny on this path
-// (400 @640^2, 1600 @1280^2; 0.1 % of the step's FLOPs), so round 1 keeps it on the VALU; the MFMA
-// QK^T variant is listed in DESIGN.md as the next step for this kernel.
+// Two implementations: flash-style fp32 VALU kernels (online softmax, one query or key per lane, the other operand streamed
+// through LDS in 64-row tiles; any dtype, the exact-fp32 parity mode) and bf16 MFMA kernels for kd = 32 / hd = 64 (forward and
+// backward, further down).  N is small on this path (400 @640^2, 1600 @1280^2).
 #include "common.h"
 
 extern "C" int y3d_get_tile_kernels(void);
