@@ -136,15 +136,24 @@ def main():
     from yolov10_3d_amd.optim import build_optimizer
     opt = build_optimizer(model)  # reference engine/trainer.py:734-790 groups; fused clip + SGD(nesterov) HIP step
     net = model
-    model.model[-1].restack()  # sibling-branch parameter stacking must be in place before DDP records parameters / buffers
+    model.model[-1].restack()  # sibling-branch parameter stacking must be in place before parameters / buffers are recorded
+    reducer = None
     if world > 1 or os.environ.get("Y3D_FORCE_DDP"):
-        net = ddp.wrap(model, device_ids=[local])
+        if os.environ.get("Y3D_TORCH_DDP"):
+            net = ddp.wrap(model, device_ids=[local])  # torch DistributedDataParallel (buckets as views)
+        else:
+            reducer = ddp.FlatGradReducer(model.parameters())  # one gather launch + one RCCL all-reduce of the flat buffer per step
+            reducer.broadcast_parameters(model)
     B, S = args.batch, args.imgsz
     batch = synth_batch(B, S, S, seed=1 + rank, device=dev)  # resident in HBM before the timed region
 
     def step():
         loss, items = net(batch)
-        ddp.scale_loss(loss, world).backward()  # reference trainer.py:401-402 (the all-reduce averages gradients)
+        if reducer is not None:
+            loss.backward()   # SUM all-reduce of the unscaled losses' gradients == reference's loss * world + averaged gradients
+            reducer.reduce()
+        else:
+            ddp.scale_loss(loss, world).backward()  # reference trainer.py:401-402 (the all-reduce averages gradients)
         opt.step(max_norm=10.0)  # clip_grad_norm_(10) + SGD nesterov (trainer.py:570-571) in three multi-tensor launches
         opt.zero_grad(set_to_none=True)
         return items

@@ -246,6 +246,10 @@ int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det
  * ---------------------------------------------------------------------------------------------- */
 int y3d_mt_sqnorm(const int64_t* grad_ptrs, const int64_t* sizes, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk,
                   float* partials, void* stream);
+/* dst_t = src_t * scale for every tensor of the table (same table layout): the step's gradient tensors -> the flat buffer that is
+ * all-reduced over RCCL (ddp.FlatGradReducer; reference: DistributedDataParallel's gradient buckets, engine/trainer.py:225-236) */
+int y3d_mt_copy(const int64_t* src_ptrs, const int64_t* dst_ptrs, const int64_t* sizes, const int* chunk_tensor, const int* chunk_off,
+                int nchunks, int chunk, float scale, void* stream);
 /* out[0] = total gradient L2 norm, out[1] = min(1, max_norm / (norm + 1e-6)) */
 int y3d_mt_clip_coef(const float* partials, int nchunks, float max_norm, float* out_norm_clip, void* stream);
 /* g = grad*clip (+ wd*p); buf = first ? g : momentum*buf + g; p -= lr * (nesterov ? g + momentum*buf : buf) */

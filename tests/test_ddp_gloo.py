@@ -65,6 +65,55 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+class _CpuReducer(ddp.FlatGradReducer):
+    """test-only: the gather launch (`y3d_mt_copy`, HIP) replaced by slot copies so that the collective logic runs over gloo on CPU"""
+
+    def _gather(self, active, grads):
+        for i, g in zip(active, grads):
+            self.views[i].copy_(g)
+
+
+def _worker_flat(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddp.init("gloo")
+    torch.manual_seed(rank)  # different initial weights per rank: broadcast_parameters must repair that
+    net = TinyNet()
+    net.c2.bias.requires_grad_(True)
+    red = _CpuReducer(net.parameters())
+    red.broadcast_parameters(net)
+    local = ddp.shard_batch(_make_batch(), rank, world)
+    for _ in range(2):  # the second step re-uses the slot views
+        for p in net.parameters():
+            p.grad = None
+        loss, _ = net(local)
+        loss.backward()
+        red.reduce()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))
+    ret[rank] = [p.grad.clone() for p in net.parameters()] + [p.detach().clone() for p in net.parameters()]
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_flat_reducer_matches_single_process():
+    """ddp.FlatGradReducer: SUM all-reduce of the unscaled per-rank losses' gradients == the single-process gradient on the global
+    batch (the reference's `loss * world_size` + averaged gradients), parameters broadcast from rank 0"""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_flat, args=(world, port, ret), nprocs=world, join=True)
+    torch.manual_seed(0)
+    net = TinyNet()
+    loss, _ = net(_make_batch())
+    loss.backward()
+    ref = [p.grad for p in net.parameters()]
+    n = len(ref)
+    for r in range(world):
+        for a, b in zip(ret[r][:n], ref):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+        for a, b in zip(ret[r][n:], net.parameters()):
+            assert torch.equal(a, b.detach())
+
+
 def test_world2_gloo_matches_single_process():
     world = 2
     port = _free_port()

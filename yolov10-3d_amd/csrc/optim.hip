@@ -77,9 +77,40 @@ __global__ __launch_bounds__(256) void mt_sgd_kernel(const long* __restrict__ pp
   }
 }
 
+// dst_t[i] = src_t[i] * scale for every tensor t of the table: gathers the step's gradient tensors into the flat all-reduce buffer
+__global__ __launch_bounds__(256) void mt_copy_kernel(const long* __restrict__ sptr, const long* __restrict__ dptr, const long* __restrict__ sizes,
+                                                      const int* __restrict__ ctensor, const int* __restrict__ coff, int chunk, float scale) {
+  const int t = ctensor[blockIdx.x];
+  const long off = (long)coff[blockIdx.x] * chunk;
+  const float* s = (const float*)sptr[t] + off;
+  float* d = (float*)dptr[t] + off;
+  long n = sizes[t] - off;
+  if (n > chunk) n = chunk;
+  if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+    const long n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 v = ((const float4*)s)[i];
+      ((float4*)d)[i] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) d[i] = s[i] * scale;
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) d[i] = s[i] * scale;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int y3d_mt_copy(const int64_t* src_ptrs, const int64_t* dst_ptrs, const int64_t* sizes, const int* chunk_tensor, const int* chunk_off,
+                int nchunks, int chunk, float scale, void* stream) {
+  Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_copy: empty chunk table");
+  hipLaunchKernelGGL(mt_copy_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)src_ptrs, (const long*)dst_ptrs,
+                     (const long*)sizes, chunk_tensor, chunk_off, chunk, scale);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
 
 int y3d_mt_sqnorm(const int64_t* grad_ptrs, const int64_t* sizes, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk,
                   float* partials, void* stream) {

@@ -7,9 +7,9 @@ Reference behaviour restated (engine/trainer.py:225-236, 280, 292, 401-402; util
     all-reduce AVERAGES gradients — so the update equals the single-process update on the global batch;
   * the only collective on the data path is that gradient all-reduce (fp32, S-3D: 120 MB per step).
 
-torch.distributed is the plumbing (backend "nccl" == RCCL on ROCm, "gloo" for the CPU tests).  Buckets are sized so that the
-head's gradients (79 % of the S-3D bytes, produced FIRST in backward — SURVEY §8e) are already in flight while the
-backbone's dgrad/wgrad kernels run.
+torch.distributed is the plumbing (backend "nccl" == RCCL on ROCm, "gloo" for the CPU tests).  Two reducers: `FlatGradReducer`
+(bench.py's N>1 path: one gather launch + one all-reduce of the flat 120 MB buffer per step) and `wrap` (torch
+DistributedDataParallel with buckets as views, kept as the drop-in for code that expects a DDP module).
 """
 from __future__ import annotations
 
@@ -62,6 +62,79 @@ def wrap(model: torch.nn.Module, device_ids=None, bucket_cap_mb: float = 32.0):
     the YOLOv10(-3D) graph receives a gradient every step, so nothing is ever 'unused'."""
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb,
                                                      gradient_as_bucket_view=True, static_graph=True)
+
+
+class FlatGradReducer:
+    """Gradient all-reduce over ONE flat fp32 buffer (S-3D: 120 MB), the data-path collective of the reference's DDP.
+
+    After backward every gradient tensor is gathered into its slot of the flat buffer by one multi-tensor launch (`y3d_mt_copy`),
+    the buffer is all-reduced (SUM: with the unscaled local losses this equals the reference's `loss * world_size` + averaged
+    gradients, trainer.py:401-402), and `p.grad` is re-pointed at the slot, so the fused optimizer runs on stable pointers.
+    Why not torch DDP: its autograd hooks copy each of the ~570 gradient tensors into a bucket view one by one (+7 % step time
+    measured at one rank); the gather is one launch at HBM rate.  Parameters without a gradient (an unused detect level) keep
+    `grad = None` on every rank and their slots stay zero."""
+
+    CHUNK = 16384
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradReducer: no parameters")
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[off:off + n].view_as(p))
+            off += n
+        self._active, self._tab = None, None
+
+    def broadcast_parameters(self, module: torch.nn.Module):
+        """rank 0's parameters and buffers to every rank (what DistributedDataParallel does when it wraps a module)"""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, 0)
+
+    def _gather(self, active, grads):
+        from ._lib import Y3DError, lib
+        from . import ops
+        dev = self.flat.device
+        if dev.type != "cuda":
+            raise Y3DError("FlatGradReducer needs gradients on a HIP device")
+        if self._active != active:
+            sizes = [self.sizes[i] for i in active]
+            ct, co = [], []
+            for t, n in enumerate(sizes):
+                for c in range((n + self.CHUNK - 1) // self.CHUNK):
+                    ct.append(t)
+                    co.append(c)
+            self._tab = {"sizes": torch.tensor(sizes, dtype=torch.int64, device=dev), "ct": torch.tensor(ct, dtype=torch.int32, device=dev),
+                         "co": torch.tensor(co, dtype=torch.int32, device=dev), "n": len(ct),
+                         "dst": torch.tensor([self.views[i].data_ptr() for i in active], dtype=torch.int64, device=dev)}
+            self._active = active
+        tb = self._tab
+        if tb.get("up") is None:
+            from .optim import PtrUploader
+            tb["up"] = PtrUploader(len(active), dev)
+        src = tb["up"].upload([g.data_ptr() for g in grads])  # non-blocking: the host must not wait for the backward to drain
+        lib().mt_copy(src.data_ptr(), tb["dst"].data_ptr(), tb["sizes"].data_ptr(), tb["ct"].data_ptr(), tb["co"].data_ptr(), tb["n"], self.CHUNK,
+                      1.0, ops.stream())
+
+    def reduce(self):
+        """gather -> all-reduce(SUM) -> p.grad = slot views.  Call after backward, before the optimizer step."""
+        active = [i for i, p in enumerate(self.params) if p.grad is not None]
+        grads = []
+        for i in active:
+            g = self.params[i].grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            grads.append(g)
+        self._gather(active, grads)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat)
+        for i in active:
+            self.params[i].grad = self.views[i]
+        return self.flat
 
 
 def scale_loss(loss: torch.Tensor, world: int) -> torch.Tensor:

@@ -14,6 +14,28 @@ from ._lib import Y3DError, lib
 CHUNK = 16384
 
 
+class PtrUploader:
+    """Pointer tables that change every step (the step's gradient tensors) go to the device through rotating PINNED host buffers
+    with a non-blocking copy: `torch.tensor(list, device=...)` stages through pageable memory and holds the host until the stream
+    has drained, which leaves the GPU idle while the rest of the optimizer's host code runs (measured ~1 ms per step)."""
+
+    def __init__(self, n, device, depth=4):
+        import numpy as np
+        self.host = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(depth)]
+        self.np = [h.numpy() for h in self.host]
+        self.dev = [torch.empty(n, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.i, self.n = 0, n
+        self._np = np
+
+    def upload(self, ptrs):
+        assert len(ptrs) == self.n
+        k = self.i
+        self.i = (self.i + 1) % len(self.host)
+        self.np[k][:] = self._np.asarray(ptrs, dtype=self._np.int64)
+        self.dev[k].copy_(self.host[k], non_blocking=True)
+        return self.dev[k]
+
+
 class FusedSGD:
     def __init__(self, param_groups, lr=0.01, momentum=0.937, nesterov=True, weight_decay=0.0):
         if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
@@ -103,7 +125,9 @@ class FusedSGD:
                 g = p.grad = g.float().contiguous()
             gkey.append(g.data_ptr())
         if gkey != st["gkey"]:
-            st["gptr"] = torch.tensor(gkey, dtype=torch.int64, device=st["dev"])
+            if st.get("gup") is None or st["gup"].n != len(gkey):
+                st["gup"] = PtrUploader(len(gkey), st["dev"])
+            st["gptr"] = st["gup"].upload(gkey)
             st["gkey"] = gkey
         return st
 
