@@ -14,6 +14,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on the host cores; a GPU box exposes every core of the node but grants 16: the default thread count then
+    # oversubscribes the OpenMP pool by an order of magnitude (a 1 s oracle step took minutes)
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(n, 16)))
 
 
 def load_golden(name):

@@ -298,6 +298,66 @@ def test_e2e_tiny2d_vs_reference_golden(dtype, tol):
         check(out["one2many"][0], g["y_eval_o2m"], 2e-3, "eval o2m")
 
 
+@pytest.mark.parametrize("name,S,B", [("yolov10m_3D.yaml", 320, 2), ("yolov10n_3D.yaml", 256, 2), ("yolov10l.yaml", 384, 1)])
+def test_full_size_scales_vs_oracle(name, S, B):
+    """the shipped model yamls at full width (BASELINE configs[2]: M + 3D head with num_scales 2 and 3x3 / 1x1 branch kernels; N + 3D head;
+    configs[3]: L, 2D) on fresh seeded inputs: one training step of the HIP path (exact-fp32 mode) against the CPU oracle restatement
+    with the same weights - loss items within 1e-3 and every parameter's gradient norm within 5e-3"""
+    import yaml as _yaml
+    import os as _os
+    from bench import synth_batch
+    y3d.set_compute_dtype(torch.float32)
+    is3d = "3D" in name
+    torch.manual_seed(1)
+    model = (y3d.YOLOv10_3DDetectionModel if is3d else y3d.YOLOv10DetectionModel)(name)
+    for m in model.modules():  # non-trivial BatchNorm state
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.9, 1.1)
+                m.bias.uniform_(-0.1, 0.1)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    nc = model.yaml["nc"]
+    batch = synth_batch(B, S, S, 5, "cpu", nc=nc)
+    # oracle
+    sub = "v10-3D" if is3d else "v10"
+    with open(_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "yolov10-3d_amd", "cfg", "models", sub, name)) as f:
+        cfg = _yaml.safe_load(f)
+    cfg["scale"] = RS.guess_scale(name)
+    spec = RS.build_spec(cfg)
+    okeys = set(RS.init_state(spec).keys())
+    st = {k: v.clone() for k, v in state.items() if k in okeys}
+    assert set(st) == okeys
+    for v in st.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    for k in list(st):
+        if "running" in k or "num_batches" in k:
+            st[k] = st[k].detach()
+    preds = RS.forward(spec, st, batch["img"], True)
+    strides = RS.model_strides(spec)
+    loss_o, items_o, _ = (RS.loss3d if is3d else RS.loss2d)(preds, batch, strides, nc)
+    loss_o.backward()
+    # HIP
+    model = model.to(DEV).train()
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    loss, items = model(dbatch)
+    loss.backward()
+    check(items, items_o.detach(), 1e-3, "loss items")
+    named = dict(model.named_parameters())
+    norms = {k: float(v.grad.norm()) for k, v in st.items() if v.requires_grad and v.grad is not None}
+    big = max(norms.values())
+    bad = []
+    for k, nv in norms.items():
+        if k in named and named[k].grad is not None:
+            if abs(float(named[k].grad.norm()) - nv) > 5e-3 * max(nv, 1e-2 * big):
+                bad.append((k, float(named[k].grad.norm()), nv))
+    assert not bad, f"{len(bad)} gradient norms differ, e.g. {bad[:3]}"
+    # (the oracle state lists the aliased head keys twice; named_parameters() reports each parameter once)
+    missing = [k for k in norms if k in named and named[k].grad is None]
+    assert not missing, f"parameters with an oracle gradient but none on the HIP path: {missing[:4]}"
+    assert sum(1 for k in norms if k in named) >= 0.5 * len(norms)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_baseline_config0_n2d_320_vs_reference_golden(dtype):
     """BASELINE.json configs[0]: the shipped YOLOv10-N 2D model (nc=80), 320x320, batch 2 — the reference's own CPU PyTorch run
