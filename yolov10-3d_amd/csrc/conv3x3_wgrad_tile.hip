@@ -29,6 +29,22 @@ struct WG3P {
 
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
+// Transposed LDS read as inline asm.  Through the builtin, hipcc (ROCm 7.2) orders every such read behind ALL outstanding LDS-DMA
+// (`s_waitcnt vmcnt(0)` before the first read of each K step), i.e. the next tile's DMA could never overlap this tile's MFMAs.
+// The asm form is invisible to that dependency tracking; the DMA'd buffer is only read after the kernel's own vmcnt(0) + barrier.
+// The result is not tracked either: `lds_wait` (below) must sit between the reads and their first use.
+__device__ __forceinline__ s16x4_t ds_tr16(const char* a) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)a));
+  return v;
+}
+// waits for every LDS read issued so far; the fragments are in/out operands so that their uses stay behind the wait
+// (N newest LDS operations may stay in flight: the next tap's fragments are issued before the current tap's are awaited)
+template <int N>
+__device__ __forceinline__ void lds_wait(s16x4_t& a, s16x4_t& b, s16x4_t& c, s16x4_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
 template <int TH>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
   typedef bf16_t T;
@@ -122,36 +138,50 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
     for (int ks = 0; ks < NPX / 32; ++ks) {  // not unrolled: 40 LDS addresses per iteration are recomputed, not kept live
       // MFMA k = 8*grp + j  <->  pixel (row 2*ks + (j>>2), x 4*grp + (j&3)): a 32-lane half reads 8 consecutive pixels per instruction
       bf16x8_t fa[2];
+      s16x4_t va[2][2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int i0 = wi * 32 + mt * 16;
         const int cch = (i0 >> 3) + (pp4 >> 1);
-        s16x4_t v[2];
 #pragma unroll
         for (int hi = 0; hi < 2; ++hi) {
           const int prow = (2 * ks + hi) * 16 + 4 * grp + qq;  // pixel index inside the tile
           const char* a = db + prow * 256 + ((cch ^ ((prow & 7) << 1)) << 4) + (pp4 & 1) * 8;
-          v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
+          va[mt][hi] = ds_tr16(a);
         }
-        fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
       }
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      // software pipeline over the taps: tap t+1's four fragment reads are issued before tap t's are awaited
+      s16x4_t vb[2][2][2];
+      auto issue_b = [&](int tap, int buf) {
         const int r = tap / 3, q = tap % 3;
-        bf16x8_t fb[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int j0 = wj * 32 + nt * 16;
           const int cch = (j0 >> 3) + (pp4 >> 1);
-          s16x4_t v[2];
 #pragma unroll
           for (int hi = 0; hi < 2; ++hi) {
             const int P = (2 * ks + hi + r) * HWD + 4 * grp + qq + q;  // halo pixel
             const char* a = hb + P * 128 + ((cch ^ (((P >> 1) & 3) << 1)) << 4) + (pp4 & 1) * 8;
-            v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
+            vb[buf][nt][hi] = ds_tr16(a);
           }
-          fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
         }
+      };
+      issue_b(0, 0);
+      lds_wait<4>(va[0][0], va[0][1], va[1][0], va[1][1]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(va[mt][0], va[mt][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int cb = tap & 1;
+        if (tap < 8) {
+          issue_b(tap + 1, cb ^ 1);
+          lds_wait<4>(vb[cb][0][0], vb[cb][0][1], vb[cb][1][0], vb[cb][1][1]);
+        } else {
+          lds_wait<0>(vb[cb][0][0], vb[cb][0][1], vb[cb][1][0], vb[cb][1][1]);
+        }
+        bf16x8_t fb[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(vb[cb][nt][0], vb[cb][nt][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
