@@ -237,7 +237,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
   int gs = 0;   // slabs retired: ring slot of (slab, tap) = (9 gs + tap) % 4 = (gs + tap) % 4
   // halo buffers as rotating byte offsets: current slab, next slab, the one being streamed into (== next when NHB == 2)
   int ho_cur = 0, ho_nxt = HBYTES, ho_tgt = (NHB - 1) * HBYTES;
-  bool tolerate = false;  // the previous tile's epilogue stores of this wave sit in the vmcnt FIFO ahead of this tile's loads
+  int tolerate = 0;  // epilogue stores of the previous tile that this wave put into the vmcnt FIFO ahead of this tile's loads (0, 8 or 16)
 #pragma unroll 1
   for (; tile < tile_end; tile += tile_step) {
     f32x4_t acc[4][8];  // [channel tile][pixel row]
@@ -249,7 +249,9 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     load_b(fb[0], ho_cur, 0, 0);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) fa[ct] = load_a1(gs & 3, ct);
-    const bool st_wave = cur.c0 + wc * 64 < p.Cn && cur.b0 + wimg < p.B;  // this wave issues the NST epilogue stores of `cur`
+    // store instructions of `cur`'s epilogue with at least one active lane: 8 per valid 32-channel pass (Cn % 64 may be 16 or 32; the
+    // compiler branches around a store whose EXEC is empty).  Counting only those is the safe side for the wait below.
+    const int st_wave = cur.b0 + wimg < p.B ? (cur.c0 + wc * 64 + 32 < p.Cn ? NST : cur.c0 + wc * 64 < p.Cn ? NST / 2 : 0) : 0;
 
 #pragma unroll 1
     for (int k = 0; k < nslab; ++k, ++gs) {
@@ -333,7 +335,9 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         } else {
           // tap t+2 was issued in stage t-1: only this stage's two loads are younger.  In a tile's first stage the previous
           // epilogue's stores are younger than the target too (vmcnt retires in order).
-          if (t == 0 && tolerate && k == 0) wvm<2 + NST>(); else wvm<2>();
+          if (t == 0 && k == 0 && tolerate == NST) wvm<2 + NST>();
+          else if (t == 0 && k == 0 && tolerate == NST / 2) wvm<2 + NST / 2>();
+          else wvm<2>();
         }
         TRC(4);
         __builtin_amdgcn_s_barrier();
@@ -341,58 +345,66 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
       }
     }
 
-    // ---- epilogue: this lane holds channels cl .. cl+7 (pass h) of pixels (wrow0 + pt, lp) of image b0 + wimg ---------------------
+    // ---- epilogue: this lane holds channels cl(h) .. cl(h)+7, h = 0 / 1, of pixels (wrow0 + pt, lp) of image b0 + wimg.  The two
+    // 64-byte halves of a pixel's 128-byte line are stored back to back: written a pass apart (8 stores later) the L2 had evicted
+    // the half-dirty line in between and re-filled it for the second half (PMC: WRITE_SIZE 1.36x the tensor, FETCH_SIZE up too) ------
     const int bb = cur.b0 + wimg;
     const bool xok = cur.x0 + lp < p.W;
+    const int cl0 = wc * 64 + lq * 8;
+    bool cok[2];
+    float ssum[2][8], ssq[2][8], sv[2][8], hv[2][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // two passes of 8 channels keep the live set small next to the 128 accumulators
-      const int cl = wc * 64 + h * 32 + lq * 8;
-      const bool cok = cur.c0 + cl < p.Cn && bb < p.B;  // Cn % 16 == 0
-      float ssum[8], ssq[8], sv[8], hv[8];
+    for (int h = 0; h < 2; ++h) {
+      cok[h] = cur.c0 + cl0 + h * 32 < p.Cn && bb < p.B;  // Cn % 16 == 0
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+      for (int i = 0; i < 8; ++i) { ssum[h][i] = 0.f; ssq[h][i] = 0.f; }
       if (EPI == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          sv[i] = cok ? p.scale[cur.g * p.Cn + cur.c0 + cl + i] : 1.f;
-          hv[i] = cok ? p.shift[cur.g * p.Cn + cur.c0 + cl + i] : 0.f;
+          sv[h][i] = cok[h] ? p.scale[cur.g * p.Cn + cur.c0 + cl0 + h * 32 + i] : 1.f;
+          hv[h][i] = cok[h] ? p.shift[cur.g * p.Cn + cur.c0 + cl0 + h * 32 + i] : 0.f;
         }
       }
+    }
 #pragma unroll
-      for (int pt = 0; pt < 8; ++pt) {
-        const int yy = cur.y0 + wrow0 + pt;
+    for (int pt = 0; pt < 8; ++pt) {
+      const int yy = cur.y0 + wrow0 + pt;
+      bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
         float v[8];
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float u = acc[2 * h + c2][pt][j];
-            if (EPI == 1) { u = u * sv[c2 * 4 + j] + hv[c2 * 4 + j]; if (p.act) u = silu_f(u); }
+            if (EPI == 1) { u = u * sv[h][c2 * 4 + j] + hv[h][c2 * 4 + j]; if (p.act) u = silu_f(u); }
             u = xok ? bf2f(f2bf(u)) : 0.f;
             v[c2 * 4 + j] = u;
-            if (EPI == 0) { ssum[c2 * 4 + j] += u; ssq[c2 * 4 + j] += u * u; }
+            if (EPI == 0) { ssum[h][c2 * 4 + j] += u; ssq[h][c2 * 4 + j] += u * u; }
           }
 #ifdef Y3D_PROBE_NOEPI
-        if (xok && cok && v[0] == 123.456f) {
+        if (xok && cok[h] && v[0] == 123.456f) {
 #else
-        if (xok && cok) {
+        if (xok && cok[h]) {
 #endif
-          bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl;
-          *(uint4*)dst = Chunk<bf16_t>::pack(v);
+          *(uint4*)(dst + h * 32) = Chunk<bf16_t>::pack(v);
         }
       }
-      if (EPI == 0 && p.part) {
-        // `red` was last read a whole tile (>= 18 barriers) ago
+    }
+    if (EPI == 0 && p.part) {
+      // `red` was last read a whole tile (>= 18 barriers) ago
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          float s = wave_xor_sum16(ssum[i]);
-          float q2 = wave_xor_sum16(ssq[i]);
+          float s = wave_xor_sum16(ssum[h][i]);
+          float q2 = wave_xor_sum16(ssq[h][i]);
           if (lp == i) {
-            red[(wp * 128 + cl + i) * 2 + 0] = s;
-            red[(wp * 128 + cl + i) * 2 + 1] = q2;
+            red[(wp * 128 + cl0 + h * 32 + i) * 2 + 0] = s;
+            red[(wp * 128 + cl0 + h * 32 + i) * 2 + 1] = q2;
           }
         }
-      }
     }
     if (EPI == 0 && p.part) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // not __syncthreads(): its fence would drain the DMA prefetch of the next tile
@@ -412,7 +424,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #ifdef Y3D_PROBE_TRACE
     ++trc_tile;
 #endif
-    tolerate = st_wave;  // at least NST stores were issued by this wave just now
+    tolerate = st_wave;
     cur = nx;
     {
       const int t2 = tile + 2 * tile_step;

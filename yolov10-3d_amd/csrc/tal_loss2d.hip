@@ -199,12 +199,22 @@ __global__ __launch_bounds__(256) void loss2d_kernel(Levels L, const unsigned ch
   if (threadIdx.x < 3) part[(long)blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
-__global__ void loss2d_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ items) {
-  int j = threadIdx.x;
-  if (j < 3) {
+__global__ __launch_bounds__(256) void loss2d_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ items) {
+  // 3 loss items x nblk block partials: 240 threads = 80 row lanes x 3 items, fp64, folded through LDS in a fixed order
+  __shared__ double sh[80][3];
+  const int t = threadIdx.x;
+  const int j = t % 3, r = t / 3;
+  if (r < 80) {
     double a = 0.0;
-    for (int i = 0; i < nblk; ++i) a += part[(long)i * 3 + j];
-    items[j] = (float)a;
+    for (int i = r; i < nblk; i += 80) a += part[(long)i * 3 + j];
+    sh[r][j] = a;
+  }
+  __syncthreads();
+  if (t < 3) {
+    double a = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 80; ++k) a += sh[k][t];
+    items[t] = (float)a;
   }
 }
 
@@ -270,7 +280,7 @@ int y3d_loss2d(int dtype, int nl, const void* const* maps, const int64_t* psw, v
   int nblk = cdiv((long)B * L.A, 256);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(loss2d_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
   else hipLaunchKernelGGL(loss2d_kernel<float>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
-  hipLaunchKernelGGL(loss2d_final_kernel, dim3(1), dim3(64), 0, st, partials, nblk, items);
+  hipLaunchKernelGGL(loss2d_final_kernel, dim3(1), dim3(256), 0, st, partials, nblk, items);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

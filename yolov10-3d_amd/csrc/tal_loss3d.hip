@@ -233,12 +233,22 @@ __global__ __launch_bounds__(256) void loss_kernel(Levels L, const unsigned char
   if (threadIdx.x < 6) part[(long)blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
-__global__ void loss_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ items) {
-  int j = threadIdx.x;
-  if (j < 6) {
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ items) {
+  // 6 loss items x nblk block partials: 240 threads = 40 row lanes x 6 items, fp64, folded through LDS in a fixed order
+  __shared__ double sh[40][6];
+  const int t = threadIdx.x;
+  const int j = t % 6, r = t / 6;
+  if (r < 40) {
     double a = 0.0;
-    for (int i = 0; i < nblk; ++i) a += part[(long)i * 6 + j];
-    items[j] = (float)a;
+    for (int i = r; i < nblk; i += 40) a += part[(long)i * 6 + j];
+    sh[r][j] = a;
+  }
+  __syncthreads();
+  if (t < 6) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 40; ++k) a += sh[k][t];
+    items[t] = (float)a;
   }
 }
 
@@ -313,7 +323,7 @@ int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, v
   int nblk = cdiv((long)B * L.A, 256);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(loss_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
   else hipLaunchKernelGGL(loss_kernel<float>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partials, nblk, items);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partials, nblk, items);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }
