@@ -133,10 +133,11 @@ def main():
     y3d.set_compute_dtype(dtype)
     torch.manual_seed(0)
     model = y3d.YOLOv10_3DDetectionModel(args.model).to(dev).train()
-    from yolov10_3d_amd.optim import build_optimizer
+    from yolov10_3d_amd.optim import ModelEMA, build_optimizer
     opt = build_optimizer(model)  # reference engine/trainer.py:734-790 groups; fused clip + SGD(nesterov) HIP step
     net = model
     model.model[-1].restack()  # sibling-branch parameter stacking must be in place before parameters / buffers are recorded
+    ema = ModelEMA(model) if rank == 0 else None  # reference: rank 0 only (engine/trainer.py:294-302), updated in optimizer_step (:574-575)
     reducer = None
     if world > 1 or os.environ.get("Y3D_FORCE_DDP"):
         if os.environ.get("Y3D_TORCH_DDP"):
@@ -156,6 +157,8 @@ def main():
             ddp.scale_loss(loss, world).backward()  # reference trainer.py:401-402 (the all-reduce averages gradients)
         opt.step(max_norm=10.0)  # clip_grad_norm_(10) + SGD nesterov (trainer.py:570-571) in three multi-tensor launches
         opt.zero_grad(set_to_none=True)
+        if ema is not None:
+            ema.update(model)  # one multi-tensor launch over the whole state_dict
         return items
 
     def sync():
@@ -236,7 +239,7 @@ def main():
             "metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"YOLOv10-S + 3D head ({args.model}), {S}x{S}, {args.dtype}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD",
+            "config": {"workload": f"YOLOv10-S + 3D head ({args.model}), {S}x{S}, {args.dtype}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
             "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None,
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],

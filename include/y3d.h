@@ -257,6 +257,17 @@ int y3d_mt_sgd(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int64_
                const float* wd, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, float momentum, int nesterov,
                int first_step, const float* norm_clip, void* stream);
 
+/* torch.optim.AdamW step (amsgrad off) — the reference's optimizer for short schedules (engine/trainer.py:752-764, `optimizer: auto`):
+ * g = grad*clip; p *= 1 - lr*wd; m += (1-beta1)(g - m); v = beta2 v + (1-beta2) g^2; p -= lr/bias_corr1 * m / (sqrt(v)/bias_corr2_sqrt + eps) */
+int y3d_mt_adamw(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int64_t* m_ptrs, const int64_t* v_ptrs, const int64_t* sizes,
+                 const float* lr, const float* wd, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, float beta1, float beta2,
+                 float eps, float bias_corr1, float bias_corr2_sqrt, const float* norm_clip, void* stream);
+/* ModelEMA.update (utils/torch_utils.py:431-443, called from optimizer_step engine/trainer.py:574-575): e = e*decay + (1-decay)*m over
+ * every floating-point state_dict tensor, reps[t] times for tensor t (the reference walks state_dict KEYS, and the aliased one-to-one
+ * head branches appear under two keys each) */
+int y3d_mt_ema(const int64_t* ema_ptrs, const int64_t* model_ptrs, const int64_t* sizes, const int* reps, const int* chunk_tensor,
+               const int* chunk_off, int nchunks, int chunk, float decay, float one_minus_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -735,6 +735,60 @@ def test_loss2d_hip_vs_reference_golden(dtype):
         check(a.grad, b.grad, tol, "d loss / d map")
 
 
+def test_fused_adamw_matches_torch():
+    """clip_grad_norm_(10) + AdamW(betas=(0.9, 0.999), per-group decay) vs torch.optim.AdamW, 4 steps (tolerance: torch's lerp /
+    addcdiv kernels may contract to FMAs, ours are compiled with -ffp-contract=off)"""
+    from yolov10_3d_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (17,), (300000,), (5, 7), (16385,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    groups = lambda ps: [{"params": ps[:3], "weight_decay": 5e-4}, {"params": ps[3:], "weight_decay": 0.0}]
+    o_ref = torch.optim.AdamW(groups(ref), lr=0.002, betas=(0.9, 0.999), weight_decay=0.0)
+    o_my = FusedAdamW(groups(mine), lr=0.002, betas=(0.9, 0.999), weight_decay=0.0)
+    for step in range(4):
+        grads = [torch.randn_like(p) * (3.0 if step == 1 else 0.01) for p in ref]  # step 1 is clipped
+        for p, q, g in zip(ref, mine, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, max_norm=10.0)
+        o_ref.step()
+        o_my.step(max_norm=10.0)
+        check(o_my.last_norm[0:1], n_ref.reshape(1), 1e-5, "grad norm")
+        for p, q in zip(ref, mine):
+            check(q, p, 2e-6, f"param after AdamW step {step}")
+
+
+def test_model_ema_matches_reference_rule():
+    """ModelEMA.update in one launch vs the reference's loop over state_dict keys (utils/torch_utils.py:431-443) on the N-3D model:
+    bit-exact, including the aliased one-to-one head tensors that the key walk updates twice per call"""
+    import copy, math
+    from yolov10_3d_amd.optim import ModelEMA
+    torch.manual_seed(0)
+    model = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml", verbose=False).to(DEV).train()
+    ema = ModelEMA(model, decay=0.9999, tau=2000)
+    ref = copy.deepcopy(ema.ema)
+    n_keys = len(ref.state_dict())
+    n_unique = len({v.data_ptr() for v in ref.state_dict().values()})
+    assert n_keys > n_unique, "the head aliases must show up as duplicate state_dict keys"
+    for upd in range(1, 4):
+        with torch.no_grad():
+            for p in model.parameters():  # the model moves between updates
+                p.add_(torch.randn_like(p) * 0.01)
+            for b in model.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(torch.rand_like(b) * 0.01)
+        ema.update(model)
+        d = 0.9999 * (1 - math.exp(-upd / 2000))
+        msd = model.state_dict()
+        with torch.no_grad():
+            for k, v in ref.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v *= d
+                    v += (1 - d) * msd[k].detach()
+        for (k, a), (_, b) in zip(ema.ema.state_dict().items(), ref.state_dict().items()):
+            assert torch.equal(a, b), f"EMA tensor {k} differs after update {upd}: max |d| = {(a.float() - b.float()).abs().max().item():.3e}"
+
+
 def test_fused_sgd_matches_torch():
     """clip_grad_norm_(10) + SGD(nesterov, weight decay) as 3 multi-tensor launches vs torch's own implementation, 3 steps"""
     from yolov10_3d_amd.optim import FusedSGD

@@ -98,6 +98,54 @@ __global__ __launch_bounds__(256) void mt_copy_kernel(const long* __restrict__ s
   }
 }
 
+
+// torch.optim.AdamW (amsgrad off, maximize off), one parameter chunk per workgroup.  bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step).
+__global__ __launch_bounds__(256) void mt_adamw_kernel(const long* __restrict__ pptr, const long* __restrict__ gptr, const long* __restrict__ mptr,
+                                                       const long* __restrict__ vptr, const long* __restrict__ sizes, const float* __restrict__ lr,
+                                                       const float* __restrict__ wd, const int* __restrict__ ctensor, const int* __restrict__ coff,
+                                                       int chunk, float beta1, float beta2, float eps, float bc1, float bc2s,
+                                                       const float* __restrict__ clip) {
+  const int t = ctensor[blockIdx.x];
+  const long off = (long)coff[blockIdx.x] * chunk;
+  float* p = (float*)pptr[t] + off;
+  const float* g = (const float*)gptr[t] + off;
+  float* m = (float*)mptr[t] + off;
+  float* v = (float*)vptr[t] + off;
+  long n = sizes[t] - off;
+  if (n > chunk) n = chunk;
+  const float c = clip ? clip[1] : 1.f, l = lr[t], w = wd[t];
+  const float step_size = l / bc1, decay = 1.f - l * w, w1 = 1.f - beta1, w2 = 1.f - beta2;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const float gv = g[i] * c;
+    const float pv = p[i] * decay;
+    const float mv = m[i] + w1 * (gv - m[i]);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float vv = v[i] * beta2 + w2 * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    p[i] = pv - step_size * (mv / (sqrtf(vv) / bc2s + eps));
+  }
+}
+
+// ModelEMA.update (utils/torch_utils.py:431-443): e = e * d + (1 - d) * m, applied reps[t] times to tensor t (an EMA tensor that the
+// reference's state_dict lists under several keys -- the aliased one-to-one head branches -- is updated once per key)
+__global__ __launch_bounds__(256) void mt_ema_kernel(const long* __restrict__ eptr, const long* __restrict__ mptr, const long* __restrict__ sizes,
+                                                     const int* __restrict__ reps, const int* __restrict__ ctensor, const int* __restrict__ coff,
+                                                     int chunk, float d, float omd) {
+  const int t = ctensor[blockIdx.x];
+  const long off = (long)coff[blockIdx.x] * chunk;
+  float* e = (float*)eptr[t] + off;
+  const float* m = (const float*)mptr[t] + off;
+  long n = sizes[t] - off;
+  if (n > chunk) n = chunk;
+  const int r = reps[t];
+  for (long i = threadIdx.x; i < n; i += 256) {
+    float ev = e[i];
+    const float mv = omd * m[i];
+    for (int k = 0; k < r; ++k) ev = ev * d + mv;
+    e[i] = ev;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -133,6 +181,27 @@ int y3d_mt_sgd(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int64_
   Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_sgd: empty chunk table");
   hipLaunchKernelGGL(mt_sgd_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)param_ptrs, (const long*)grad_ptrs,
                      (const long*)buf_ptrs, (const long*)sizes, lr, wd, chunk_tensor, chunk_off, chunk, momentum, nesterov, first_step, norm_clip);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_mt_adamw(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int64_t* m_ptrs, const int64_t* v_ptrs, const int64_t* sizes,
+                 const float* lr, const float* wd, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, float beta1, float beta2,
+                 float eps, float bias_corr1, float bias_corr2_sqrt, const float* norm_clip, void* stream) {
+  Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_adamw: empty chunk table");
+  Y3D_CHECK(bias_corr1 > 0.f && bias_corr2_sqrt > 0.f, "mt_adamw: bias corrections must be positive (step >= 1)");
+  hipLaunchKernelGGL(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)param_ptrs, (const long*)grad_ptrs,
+                     (const long*)m_ptrs, (const long*)v_ptrs, (const long*)sizes, lr, wd, chunk_tensor, chunk_off, chunk, beta1, beta2, eps,
+                     bias_corr1, bias_corr2_sqrt, norm_clip);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_mt_ema(const int64_t* ema_ptrs, const int64_t* model_ptrs, const int64_t* sizes, const int* reps, const int* chunk_tensor,
+               const int* chunk_off, int nchunks, int chunk, float decay, float one_minus_decay, void* stream) {
+  Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_ema: empty chunk table");
+  hipLaunchKernelGGL(mt_ema_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)ema_ptrs, (const long*)model_ptrs,
+                     (const long*)sizes, reps, chunk_tensor, chunk_off, chunk, decay, one_minus_decay);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

@@ -1,10 +1,14 @@
-"""Fused optimizer step: gradient clipping + SGD(Nesterov) over all parameters in three HIP launches.
+"""Fused optimizer step: gradient clipping + SGD(Nesterov) or AdamW over all parameters in three HIP launches, + ModelEMA in one.
 
-Reference recipe (engine/trainer.py:567-575): unscale -> clip_grad_norm_(max_norm=10) -> optimizer.step -> zero_grad, with the three
-parameter groups of build_optimizer (:734-790: weights with decay, norm weights without, biases without).  Semantics are
-torch.optim.SGD's (dampening 0) and torch.nn.utils.clip_grad_norm_'s.
+Reference recipe (engine/trainer.py:567-575): unscale -> clip_grad_norm_(max_norm=10) -> optimizer.step -> zero_grad -> ema.update,
+with the three parameter groups of build_optimizer (:734-790: weights with decay, norm weights without, biases without; SGD with
+nesterov for long schedules, AdamW(betas=(momentum, 0.999)) for short ones).  Semantics are torch.optim.SGD's (dampening 0),
+torch.optim.AdamW's (amsgrad off), torch.nn.utils.clip_grad_norm_'s and utils/torch_utils.py:416-443's ModelEMA.
 """
 from __future__ import annotations
+
+import copy
+import math
 
 import torch
 
@@ -37,6 +41,8 @@ class PtrUploader:
 
 
 class FusedSGD:
+    NSTATE = 1  # flat zero-initialised state buffers per parameter (SGD: momentum)
+
     def __init__(self, param_groups, lr=0.01, momentum=0.937, nesterov=True, weight_decay=0.0):
         if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
             param_groups = [{"params": list(param_groups)}]
@@ -77,10 +83,10 @@ class FusedSGD:
         old = self._state
         if old is None:
             sizes_all = [p.numel() for p in self.params]
-            flat = torch.zeros(sum(sizes_all), dtype=torch.float32, device=dev)  # momentum buffers, one allocation
+            flat = torch.zeros(self.NSTATE, sum(sizes_all), dtype=torch.float32, device=dev)  # state buffers, one allocation
             bufs, off = [], 0
             for n in sizes_all:
-                bufs.append(flat[off:off + n])
+                bufs.append(flat[:, off:off + n])
                 off += n
         else:
             flat, bufs = old["flat"], old["bufs"]
@@ -96,7 +102,8 @@ class FusedSGD:
         st = {
             "dev": dev, "flat": flat, "bufs": bufs, "nchunks": len(ct), "active": list(active),
             "sizes": i64(sizes), "ctensor": torch.tensor(ct, dtype=torch.int32, device=dev), "coff": torch.tensor(co, dtype=torch.int32, device=dev),
-            "bptr": i64([bufs[i].data_ptr() for i in active]), "partials": torch.empty(len(ct), dtype=torch.float32, device=dev),
+            "bptr": i64([bufs[i][0].data_ptr() for i in active]),
+            "bptr2": i64([bufs[i][1].data_ptr() for i in active]) if self.NSTATE > 1 else None, "partials": torch.empty(len(ct), dtype=torch.float32, device=dev),
             "norm_clip": torch.empty(2, dtype=torch.float32, device=dev), "pkey": None, "gkey": None,
             "lr": torch.tensor([lr_all[i] for i in active], dtype=torch.float32, device=dev),
             "wd": torch.tensor([wd_all[i] for i in active], dtype=torch.float32, device=dev),
@@ -143,10 +150,13 @@ class FusedSGD:
             L.mt_clip_coef(st["partials"].data_ptr(), st["nchunks"], float(max_norm), st["norm_clip"].data_ptr(), s)
             clip = st["norm_clip"].data_ptr()
             self.last_norm = st["norm_clip"]
+        self._steps += 1
+        self._update(L, st, clip, s)
+
+    def _update(self, L, st, clip, s):
         L.mt_sgd(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["sizes"].data_ptr(), st["lr"].data_ptr(),
                  st["wd"].data_ptr(), st["ctensor"].data_ptr(), st["coff"].data_ptr(), st["nchunks"], CHUNK, self.momentum, int(self.nesterov),
                  0, clip, s)
-        self._steps += 1
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -156,8 +166,107 @@ class FusedSGD:
                 p.grad.zero_()
 
 
-def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
-    """the reference's three parameter groups (engine/trainer.py:766-790): biases, weights (decay), normalisation weights"""
+class FusedAdamW(FusedSGD):
+    """torch.optim.AdamW(betas, eps, weight_decay per group), amsgrad off; same tables and clipping as FusedSGD"""
+    NSTATE = 2  # exp_avg, exp_avg_sq
+
+    def __init__(self, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(param_groups, lr=lr, momentum=betas[0], nesterov=False, weight_decay=weight_decay)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+
+    def _update(self, L, st, clip, s):
+        b1, b2 = self.betas
+        bc1 = 1.0 - b1 ** self._steps
+        bc2s = math.sqrt(1.0 - b2 ** self._steps)
+        L.mt_adamw(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["bptr2"].data_ptr(), st["sizes"].data_ptr(),
+                   st["lr"].data_ptr(), st["wd"].data_ptr(), st["ctensor"].data_ptr(), st["coff"].data_ptr(), st["nchunks"], CHUNK, b1, b2,
+                   self.eps, bc1, bc2s, clip, s)
+
+
+class ModelEMA:
+    """utils/torch_utils.py:416-443: exponential moving average of every floating-point state_dict tensor (parameters AND
+    BatchNorm running statistics), decay ramp `decay * (1 - exp(-updates / tau))`, one multi-tensor launch per update.
+
+    The reference walks the EMA model's state_dict KEYS; the one-to-one head branches are registered under two names each
+    (`o2o_heads.*` and `cls/o2d/...`, nn/modules/head.py:627-629), so those tensors receive the update twice per call.  The table
+    keeps that multiplicity (`reps`), because matching the reference's EMA weights bit for bit needs it."""
+
+    def __init__(self, model, decay=0.9999, tau=2000, updates=0):
+        self.ema = copy.deepcopy(model).eval()
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / tau))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self.enabled = True
+        self._tab = None
+
+    def _tables(self, model):
+        esd = self.ema.state_dict(keep_vars=True)   # keep_vars: the live tensors, so that re-pointed storage is noticed
+        msd = model.state_dict(keep_vars=True)
+        pairs, index = [], {}
+        for k, v in esd.items():
+            if not v.dtype.is_floating_point:
+                continue
+            m = msd[k]
+            if v.dtype != torch.float32 or m.dtype != torch.float32 or not (v.is_contiguous() and m.is_contiguous()):
+                raise Y3DError(f"ModelEMA: {k} must be a contiguous fp32 tensor on both models")
+            if v.shape != m.shape:
+                raise Y3DError(f"ModelEMA: {k} has shape {tuple(v.shape)} in the EMA model and {tuple(m.shape)} in the model")
+            j = index.get(v.data_ptr())
+            if j is None:
+                index[v.data_ptr()] = len(pairs)
+                pairs.append([v, m, 1])
+            else:
+                pairs[j][2] += 1
+        dev = pairs[0][0].device
+        if dev.type != "cuda":
+            raise Y3DError("ModelEMA needs the models on a HIP device")
+        ct, co = [], []
+        for t, (v, _, _) in enumerate(pairs):
+            for c in range((v.numel() + CHUNK - 1) // CHUNK):
+                ct.append(t)
+                co.append(c)
+        i64 = lambda x: torch.tensor(x, dtype=torch.int64, device=dev)
+        i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=dev)
+        self._tab = {"pairs": pairs, "n": len(ct), "sizes": i64([v.numel() for v, _, _ in pairs]), "reps": i32([r for _, _, r in pairs]),
+                     "ct": i32(ct), "co": i32(co), "ekey": None, "mkey": None, "model": model}
+        return self._tab
+
+    @torch.no_grad()
+    def update(self, model):
+        if not self.enabled:
+            return
+        self.updates += 1
+        d = self.decay(self.updates)
+        tb = self._tab
+        if tb is None or tb["model"] is not model:
+            tb = self._tables(model)
+        ekey = [v.data_ptr() for v, _, _ in tb["pairs"]]
+        mkey = [m.data_ptr() for _, m, _ in tb["pairs"]]
+        if len(set(ekey)) != len(ekey):  # storage re-pointed so that entries merged or split: rebuild the multiplicities
+            tb = self._tables(model)
+            ekey = [v.data_ptr() for v, _, _ in tb["pairs"]]
+            mkey = [m.data_ptr() for _, m, _ in tb["pairs"]]
+        dev = tb["sizes"].device
+        if ekey != tb["ekey"]:
+            tb["eptr"], tb["ekey"] = torch.tensor(ekey, dtype=torch.int64, device=dev), ekey
+        if mkey != tb["mkey"]:
+            tb["mptr"], tb["mkey"] = torch.tensor(mkey, dtype=torch.int64, device=dev), mkey
+        lib().mt_ema(tb["eptr"].data_ptr(), tb["mptr"].data_ptr(), tb["sizes"].data_ptr(), tb["reps"].data_ptr(), tb["ct"].data_ptr(),
+                     tb["co"].data_ptr(), tb["n"], CHUNK, float(d), float(1 - d), ops.stream())
+
+    def update_attr(self, model, include=(), exclude=("process_group", "reducer")):
+        """utils/torch_utils.py:445-448 / copy_attr :342-349"""
+        if self.enabled:
+            for k, v in model.__dict__.items():
+                if (len(include) and k not in include) or k.startswith("_") or k in exclude:
+                    continue
+                setattr(self.ema, k, v)
+
+
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, name="SGD"):
+    """the reference's three parameter groups (engine/trainer.py:766-790): biases, weights (decay), normalisation weights;
+    name: "SGD" (nesterov) or "AdamW" (betas = (momentum, 0.999)), as :775-781"""
     g = [], [], []
     bn = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k)
     seen = set()
@@ -172,5 +281,9 @@ def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
                 g[1].append(p)
             else:
                 g[0].append(p)
-    return FusedSGD([{"params": g[2], "weight_decay": 0.0}, {"params": g[0], "weight_decay": decay}, {"params": g[1], "weight_decay": 0.0}],
-                    lr=lr, momentum=momentum, nesterov=True)
+    groups = [{"params": g[2], "weight_decay": 0.0}, {"params": g[0], "weight_decay": decay}, {"params": g[1], "weight_decay": 0.0}]
+    if name == "AdamW":
+        return FusedAdamW(groups, lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+    if name != "SGD":
+        raise NotImplementedError(f"optimizer {name!r}: the hot path provides SGD and AdamW (engine/trainer.py:775-785)")
+    return FusedSGD(groups, lr=lr, momentum=momentum, nesterov=True)
