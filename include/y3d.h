@@ -239,6 +239,14 @@ int y3d_v10_postprocess_scratch_floats(int B, int A, int nc, int max_det); /* 0 
 int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
                         int64_t* labels, float* scratch, void* stream);
 
+/* KITTI decode of the post-processed detections (data/datasets/kitti.py:519-576 `decode_preds`, called by the validator's
+ * `_prepare_preds`, models/yolov10_3D/val.py:210-214).  preds (B, K, 37) fp32 rows [xyxy | centre-3d | size residual | 24 heading |
+ * depth | depth log-variance | score logit | label]; calib (B, 6) = (cu, cv, fu, fv, tx, ty) of the original image; ratio (B, 2) =
+ * ratio_pad[i][0]; inv_trans (B, 2, 3) or NULL (undo_augment = False: the fixed 1242/1280, 375/384 rescale); mean_size (nc, 3).
+ * out (B, K, 14) f64 [cls, alpha, x1, y1, x2, y2, h, w, l, x, y, z, ry, score]; keep (B, K) u8 = !(score < threshold). */
+int y3d_kitti_decode(const float* preds, int B, int K, const double* calib, const double* ratio, const double* inv_trans,
+                     const double* mean_size, int nc, int use_camera_dis, double threshold, double* out, unsigned char* keep, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step as multi-tensor launches (optim.hip): clip_grad_norm_ + SGD(nesterov, weight decay) — engine/trainer.py:567-575,
  * 734-790.  All table arguments are DEVICE arrays: tensor t has sizes[t] fp32 elements at param_ptrs[t] / grad_ptrs[t] / buf_ptrs[t];

@@ -850,3 +850,71 @@ def fold_conv_bn(w, gamma, beta, mean, var, eps=BN_EPS):
 def fold_repvggdw(w7, b7, w3, b3):
     """block.py:716-735 RepVGGDW.fuse: pad the folded 3x3 into the folded 7x7."""
     return w7 + F.pad(w3, [2, 2, 2, 2]), b7 + b3
+
+
+# --------------------------------------------------------------------------------------
+# KITTI decode of the post-processed predictions  (data/datasets/kitti.py:519-576 decode_preds; helpers:
+# data/datasets/decode_helper.py:12-18 bin2angle, data/datasets/kitti_utils.py:241-251 img_to_rect, :286-299
+# camera_dis_to_rect, :311-325 alpha2ry, :467-470 affine_transform)
+# --------------------------------------------------------------------------------------
+KITTI_MEAN_SIZE = ((1.52563191462, 1.62856739989, 3.88311640418), (1.76255119, 0.66068622, 0.84422524),
+                   (1.73698127, 0.59706367, 1.76282397))  # kitti.py:38-41, (h, w, l) per class
+
+
+def kitti_decode(preds, calib, ratio, inv_trans, mean_size=KITTI_MEAN_SIZE, threshold=0.001, use_camera_dis=False):
+    """preds (B, K, 37) fp32 rows [xyxy 4 | center3d 2 | size3d 3 | heading 24 | depth | depth log-variance | score logit | label]
+    (`v10_3Dpostprocess` output, validator layout); calib (B, 6) = (cu, cv, fu, fv, tx, ty) of the ORIGINAL image (the reference
+    reads them from its float32 P2 matrix); ratio (B, 2) = ratio_pad[i][0]; inv_trans (B, 2, 3) or None (undo_augment=False).
+    -> rows (B, K, 14) float64 [cls, alpha, x1, y1, x2, y2, h, w, l, x, y, z, ry, score], keep (B, K) bool (score >= threshold).
+    The reference computes these per detection in numpy with float32 inputs promoted to float64 by the calibration constants;
+    the dtype of every intermediate below follows that code."""
+    import numpy as np
+    P = preds.detach().cpu().float().numpy()
+    B, K, _ = P.shape
+    calib = np.asarray(calib, dtype=np.float64).reshape(B, 6)
+    ratio = np.asarray(ratio, dtype=np.float64).reshape(B, 2)
+    ms = np.asarray(mean_size, dtype=np.float64)
+    out = np.zeros((B, K, 14), dtype=np.float64)
+    keep = np.zeros((B, K), dtype=bool)
+    bins = P[..., 9:21].argmax(-1)                                            # first maximum, as torch.argmax
+    res = np.take_along_axis(P[..., 21:33], bins[..., None], -1)[..., 0]      # float32
+    ang = (bins.astype(np.float32) * np.float32(2 * math.pi / 12.0)) + res    # torch: int64 * python float -> float32
+    ang = np.where(ang > np.float32(math.pi), ang - np.float32(2 * math.pi), ang).astype(np.float32)
+    sig = 1.0 / (1.0 + np.exp(-P[..., 35].astype(np.float32)))               # torch.sigmoid in float32
+    for i in range(B):
+        cu, cv, fu, fv, tx, ty = calib[i]
+        for j in range(K):
+            r = P[i, j]
+            cid = int(r[36])
+            box = r[0:4].astype(np.float64) / ratio[i][[0, 1, 0, 1]]
+            x = (box[0] + box[2]) / 2
+            dim = (r[6:9] + ms[cid]).astype(np.float32)                       # in-place add on the float32 view
+            depth = np.float64(r[33])
+            sigma = float(np.exp(np.float32(-r[34])))                         # torch.exp in float32, then .item()
+            if inv_trans is not None:
+                t = np.asarray(inv_trans[i], dtype=np.float64).reshape(2, 3)
+                c3 = t @ np.array([r[4], r[5], 1.0], dtype=np.float32).astype(np.float64)
+                u, v = c3[0], c3[1]
+            else:
+                u = np.float64(np.float32(r[4] * np.float32(1242)) / np.float32(1280.0))
+                v = np.float64(np.float32(r[5] * np.float32(375)) / np.float32(384.0))
+            if use_camera_dis:
+                fd = np.sqrt((u - cu) ** 2 + (v - cv) ** 2 + fu ** 2)
+                lx = ((u - cu) * depth) / fd + tx
+                ly = ((v - cv) * depth) / fd + ty
+                lz = np.sqrt(depth ** 2 - lx ** 2 - ly ** 2)
+            else:
+                lx = ((u - cu) * depth) / fu + tx
+                ly = ((v - cv) * depth) / fv + ty
+                lz = depth
+            ly = ly + np.float64(dim[0]) / 2
+            alpha = float(ang[i, j])
+            ry = alpha + np.arctan2(x - cu, fu)
+            if ry > np.pi:
+                ry -= 2 * np.pi
+            if ry < -np.pi:
+                ry += 2 * np.pi
+            score = float(sig[i, j]) * sigma
+            out[i, j] = [cid, alpha, *box, *dim.astype(np.float64), lx, ly, lz, ry, score]
+            keep[i, j] = not (score < threshold)
+    return out, keep

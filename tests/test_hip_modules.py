@@ -735,6 +735,35 @@ def test_loss2d_hip_vs_reference_golden(dtype):
         check(a.grad, b.grad, tol, "d loss / d map")
 
 
+def test_kitti_decode_vs_oracle_and_golden():
+    """y3d_kitti_decode (one launch over B*K rows) vs the restated decode_preds and the reference's own rows (golden), three modes;
+    then the dict-of-lists form the validator consumes"""
+    from yolov10_3d_amd import kitti
+    g = load_golden("kitti_decode")
+    preds = g["preds"].to(DEV)
+    files = [f"{i:06d}.png" for i in range(preds.shape[0])]
+    for tag, undo, cam in (("aug", True, False), ("noaug", False, False), ("camdis", True, True)):
+        rows, keep = kitti.decode_preds_device(preds, g["calib"], g["ratio"], g["inv_trans"], undo_augment=undo, use_camera_dis=cam)
+        r_ref, k_ref = RS.kitti_decode(g["preds"], g["calib"], g["ratio"], g["inv_trans"] if undo else None, use_camera_dis=cam)
+        assert torch.equal(keep.cpu(), torch.from_numpy(k_ref)), "threshold decisions are exact"
+        torch.testing.assert_close(rows.cpu(), torch.from_numpy(r_ref), rtol=1e-6, atol=1e-6)  # f64 math; expf / atan2 differ in the last ulp
+        res = kitti.decode_preds_eval(preds, g["calib"], files, g["ratio"], g["inv_trans"], undo_augment=undo, use_camera_dis=cam)
+        cnt = g[f"count_{tag}"].long()
+        for i, f in enumerate(files):
+            assert len(res[f]) == int(cnt[i]) and all(len(t) == 14 for t in res[f])
+            torch.testing.assert_close(torch.tensor(res[f], dtype=torch.float64), g[f"rows_{tag}"][i, :int(cnt[i])].double(), rtol=1e-5, atol=1e-5)
+    # after the real post-processing kernel: rows of v10_3Dpostprocess feed the decode unchanged
+    gp = load_golden("post3d")
+    reg, sc, lab = y3d.loss.v10_3Dpostprocess(gp["preds"].to(DEV), 50, 3)
+    full = torch.cat((reg, sc.unsqueeze(-1), lab.unsqueeze(-1).float()), -1)  # models/yolov10_3D/val.py:46-47
+    B = full.shape[0]
+    calib, ratio = g["calib"][:1].expand(B, 6), g["ratio"][:1].expand(B, 2)
+    rows, keep = kitti.decode_preds_device(full, calib, ratio, None, undo_augment=False)
+    r_ref, k_ref = RS.kitti_decode(full.cpu(), calib, ratio, None)
+    assert torch.equal(keep.cpu(), torch.from_numpy(k_ref))
+    torch.testing.assert_close(rows.cpu(), torch.from_numpy(r_ref), rtol=1e-6, atol=1e-6)
+
+
 def test_fused_adamw_matches_torch():
     """clip_grad_norm_(10) + AdamW(betas=(0.9, 0.999), per-group decay) vs torch.optim.AdamW, 4 steps (tolerance: torch's lerp /
     addcdiv kernels may contract to FMAs, ours are compiled with -ffp-contract=off)"""

@@ -192,6 +192,20 @@ def test_postprocess():
     close(sc, g["scores"])
 
 
+def test_kitti_decode():
+    """decode_preds (kitti.py:519-576): with the inverse affine, without it (fixed 1242/1280, 375/384 rescale), camera-distance mode"""
+    g = load_golden("kitti_decode")
+    for tag, inv, cam in (("aug", g["inv_trans"], False), ("noaug", None, False), ("camdis", g["inv_trans"], True)):
+        rows, keep = RS.kitti_decode(g["preds"], g["calib"], g["ratio"], inv, use_camera_dis=cam)
+        cnt = g[f"count_{tag}"].long()
+        assert keep.sum(1).tolist() == cnt.tolist(), "detections under the 0.001 score threshold are dropped"
+        assert 0 < int(cnt.min()) and int(cnt.max()) < rows.shape[1]
+        for i in range(rows.shape[0]):
+            mine = torch.from_numpy(rows[i][keep[i]])
+            ref = g[f"rows_{tag}"][i, :int(cnt[i])].double()
+            torch.testing.assert_close(mine, ref, rtol=1e-5, atol=1e-5)  # the fixture is float32-accurate (numpy 2 scalar rules)
+
+
 def tiny_cfg(name, **over):
     with open(os.path.join(ROOT, "yolov10-3d_amd", "cfg", "models", name)) as f:
         d = yaml.safe_load(f)

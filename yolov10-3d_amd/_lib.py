@@ -16,7 +16,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "y3d.h")
 
 F32, BF16 = 0, 1
 
-_CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
+_CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 class Y3DError(RuntimeError):

@@ -177,6 +177,68 @@ inline int ew_grid(long total) {
   return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
 }
 
+
+// KITTI decode of the post-processed rows (data/datasets/kitti.py:519-576): one thread per detection.  The reference promotes the
+// float32 predictions to float64 through the calibration constants; the float32 steps (heading angle, sigmoid, exp, size residual)
+// are kept in float32 here as there.
+__global__ __launch_bounds__(256) void kitti_decode_kernel(const float* __restrict__ preds, int B, int K, const double* __restrict__ calib,
+                                                           const double* __restrict__ ratio, const double* __restrict__ inv_trans,
+                                                           const double* __restrict__ mean_size, int nc, int use_camera_dis, double threshold,
+                                                           double* __restrict__ out, unsigned char* __restrict__ keep) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * K) return;
+  const int i = idx / K;
+  const float* r = preds + (long)idx * 37;
+  const double cu = calib[i * 6 + 0], cv = calib[i * 6 + 1], fu = calib[i * 6 + 2], fv = calib[i * 6 + 3], tx = calib[i * 6 + 4], ty = calib[i * 6 + 5];
+  const double rw = ratio[i * 2 + 0], rh = ratio[i * 2 + 1];
+  int cid = (int)r[36];
+  const int cm = cid < 0 ? 0 : (cid >= nc ? nc - 1 : cid);  // the reference would raise on a label outside the mean-size table
+  // heading: first maximum of the 12 bin logits, residual of that bin (decode_helper.py:12-18, float32)
+  int bin = 0;
+  float best = r[9];
+  for (int k = 1; k < 12; ++k) if (r[9 + k] > best) { best = r[9 + k]; bin = k; }
+  const float PI_F = 3.14159265358979323846f;
+  float ang = (float)bin * (float)(2.0 * 3.14159265358979323846 / 12.0) + r[21 + bin];
+  if (ang > PI_F) ang = ang - (float)(2.0 * 3.14159265358979323846);
+  const double alpha = (double)ang;
+  const double x1 = (double)r[0] / rw, y1 = (double)r[1] / rh, x2 = (double)r[2] / rw, y2 = (double)r[3] / rh;
+  const double xc = (x1 + x2) / 2;
+  const float h = r[6] + (float)mean_size[cm * 3 + 0], w = r[7] + (float)mean_size[cm * 3 + 1], l = r[8] + (float)mean_size[cm * 3 + 2];
+  const double depth = (double)r[33];
+  const double sigma = (double)expf(-r[34]);
+  double u, v;
+  if (inv_trans) {
+    const double* t = inv_trans + i * 6;
+    u = t[0] * (double)r[4] + t[1] * (double)r[5] + t[2];
+    v = t[3] * (double)r[4] + t[4] * (double)r[5] + t[5];
+  } else {
+    u = (double)((r[4] * 1242.f) / 1280.f);
+    v = (double)((r[5] * 375.f) / 384.f);
+  }
+  double lx, ly, lz;
+  if (use_camera_dis) {  // kitti_utils.py:286-299
+    const double fd = sqrt((u - cu) * (u - cu) + (v - cv) * (v - cv) + fu * fu);
+    lx = ((u - cu) * depth) / fd + tx;
+    ly = ((v - cv) * depth) / fd + ty;
+    lz = sqrt(depth * depth - lx * lx - ly * ly);
+  } else {               // kitti_utils.py:241-251
+    lx = ((u - cu) * depth) / fu + tx;
+    ly = ((v - cv) * depth) / fv + ty;
+    lz = depth;
+  }
+  ly += (double)h / 2;
+  const double PI_D = 3.14159265358979323846;
+  double ry = alpha + atan2(xc - cu, fu);  // kitti_utils.py:311-325
+  if (ry > PI_D) ry -= 2 * PI_D;
+  if (ry < -PI_D) ry += 2 * PI_D;
+  const float sg = 1.f / (1.f + expf(-r[35]));
+  const double score = (double)sg * sigma;
+  double* o = out + (long)idx * 14;
+  o[0] = (double)cid; o[1] = alpha; o[2] = x1; o[3] = y1; o[4] = x2; o[5] = y2; o[6] = (double)h; o[7] = (double)w; o[8] = (double)l;
+  o[9] = lx; o[10] = ly; o[11] = lz; o[12] = ry; o[13] = score;
+  keep[idx] = score < threshold ? 0 : 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -253,6 +315,16 @@ int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det
   Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: max_det * nc = %d does not fit LDS", max_det * nc);
   (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_kitti_decode(const float* preds, int B, int K, const double* calib, const double* ratio, const double* inv_trans,
+                     const double* mean_size, int nc, int use_camera_dis, double threshold, double* out, unsigned char* keep, void* stream) {
+  Y3D_CHECK(B >= 1 && K >= 1 && nc >= 1, "kitti_decode: B, K, nc must be positive");
+  Y3D_CHECK(preds && calib && ratio && mean_size && out && keep, "kitti_decode: null argument");
+  hipLaunchKernelGGL(kitti_decode_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, preds, B, K, calib, ratio, inv_trans, mean_size,
+                     nc, use_camera_dis, threshold, out, keep);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }
