@@ -246,7 +246,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

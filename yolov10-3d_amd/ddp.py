@@ -25,6 +25,8 @@ def init(backend: str | None = None, device: torch.device | None = None):
     rank = int(os.environ.get("RANK", "0"))
     if (world > 1 or os.environ.get("Y3D_FORCE_DDP")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29500")  # single-rank rehearsal without a launcher
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
