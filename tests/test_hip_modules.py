@@ -590,7 +590,9 @@ def test_tal3d_hip_on_assigner_fixture_scale():
                                   (256, 256, 3, 1, 4, 16, 16, 2), (2048, 2048, 3, 1, 16, 40, 40, 2),
                                   # odd batch against the 2- / 4-image tiles, partial column tiles, 96 / 192 / 320 channels, one image
                                   (96, 192, 3, 1, 1, 16, 24, 3), (128, 64, 3, 1, 1, 8, 40, 5), (192, 320, 3, 1, 1, 24, 24, 1),
-                                  (256, 128, 3, 1, 2, 32, 16, 7)])
+                                  (256, 128, 3, 1, 2, 32, 16, 7),
+                                  # input channels per group = 96 / 160: the wgrad tile's last 64-channel slab is half empty
+                                  (96, 96, 3, 1, 1, 16, 32, 2), (192, 192, 3, 1, 2, 8, 16, 3), (160, 64, 3, 1, 1, 12, 20, 1)])
 def test_tile_kernels_agree_with_generic_kernels(case):
     """A/B inside one process: the resident-tile kernels (conv3x3_tile / conv3x3_wgrad_tile) and the generic implicit-GEMM
     kernels compute the same bf16 products with fp32 accumulation, so forward, dx and dW must agree to accumulation-order noise."""

@@ -16,6 +16,9 @@ SHAPES = [  # B, H, W, Cin, Cout, k, s, g
     (32, 80, 80, 64, 64, 3, 1, 1),
     (32, 40, 40, 384, 256, 1, 1, 1),      # 1x1
     (32, 80, 80, 64, 128, 3, 2, 1),       # stride 2
+    (32, 80, 80, 96, 96, 3, 1, 1),        # M-3D body (channel counts that are multiples of 32, not 64)
+    (32, 40, 40, 192, 192, 3, 1, 1),
+    (32, 160, 160, 48, 48, 3, 1, 1),
 ]
 
 def main():

@@ -11,6 +11,7 @@
 // half touches per read sit in eight different 32-byte bank groups (conflict-free for both images).
 // Split-K over pixel-tile ranges into fp32 slabs; the existing wgrad_reduce kernel sums them into the OIHW gradient.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
     for (int rd = 0; rd < HR; ++rd) {
       if (rd * NT + tid < HCH) {
         int yy = y0 + h_y[rd] - 1, xx = x0 + h_x[rd] - 1;
-        bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && ci0 + h_c[rd] < p.Cg;  // Cg % 64 == 32: the last slab is half zeros
         const T* src = ok ? X + (long)b * p.xsb + (long)yy * p.xsh + (long)xx * p.xsw + (long)g * p.Cg + ci0 + h_c[rd] : zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(hb + (rd * NT + wave * 64) * 16), 16, 0, 0);
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           int co = c0 + wi * 32 + mt * 16 + (lane >> 4) * 4 + rg;
-          if (co < p.Cn) slab[(long)co * Ktot + tap * p.Cg + ci] = acc[tap][mt][nt][rg];
+          if (co < p.Cn && ci < p.Cg) slab[(long)co * Ktot + tap * p.Cg + ci] = acc[tap][mt][nt][rg];
         }
       }
 }
@@ -233,7 +234,7 @@ int launch_wg(const WG3P& p, int nsplit, hipStream_t st) {
 // tile height of the resident wgrad kernel for this geometry (bf16 only), 0 -> generic split-K kernel
 int y3d_wgrad_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad) {
   if (dtype != Y3D_BF16 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return 0;
-  if (Cg % 64 != 0 || Cn % 8 != 0 || W < 8) return 0;
+  if (Cg % 32 != 0 || Cg < 64 || Cn % 8 != 0 || W < 8) return 0;  // 96 / 160 / ... channels: the last 64-channel slab is half empty
   if (H % 8 == 0) return 8;
   if (H % 4 == 0) return 4;
   return 0;
@@ -241,8 +242,13 @@ int y3d_wgrad_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int k
 
 int y3d_wgrad_tile_splits(int th, int B, int H, int W, int Cg, int Cn, int G) {
   long ntiles = (long)B * (H / th) * cdiv(W, 16);
-  long blocks = (long)(Cg / 64) * cdiv(Cn, 128) * G;
-  long want = cdiv(512, blocks);
+  long blocks = (long)cdiv(Cg, 64) * cdiv(Cn, 128) * G;
+  // one round of workgroups: TH = 8 leaves room for one workgroup per CU (112 KB LDS), TH = 4 for two.  More splits only add slab
+  // traffic (each workgroup writes its 9 x 128 x 64 fp32 accumulators) and a ragged second round: 512 -> 256 measured +2 % on the
+  // head layers, +12 % at 40x40, +35-40 % on 96- / 192-channel body layers
+  static int target8 = 0;
+  if (!target8) { const char* e = getenv("Y3D_WG_TARGET"); target8 = e ? atoi(e) : 256; }
+  long want = cdiv(th == 8 ? target8 : 2 * target8, blocks);
   if (want > ntiles) want = ntiles;
   long slab_bytes = (long)G * Cn * 9 * Cg * 4;
   long cap = (64L << 20) / slab_bytes;  // keep the fp32 partial slabs of one layer under ~64 MB
@@ -262,7 +268,7 @@ int y3d_conv3x3_wgrad_tile_launch(int th, const void* x, long xsb, long xsh, lon
   p.ntx = cdiv(W, 16); p.nty = H / th;
   p.ntiles = B * p.nty * p.ntx;
   p.tiles_per_split = cdiv(p.ntiles, nsplit);
-  p.nslab = Cg / 64;
+  p.nslab = cdiv(Cg, 64);
   hipStream_t st = (hipStream_t)stream;
   if (th == 8) return launch_wg<8>(p, nsplit, st);
   return launch_wg<4>(p, nsplit, st);

@@ -405,7 +405,7 @@ class v10Detect3d(nn.Module):
                 z2 = ops.FusedConvBNActFn.apply(z1, s2, len(branches), None, *s2.params())
                 out = ops.HeadProjSlicesFn.apply(z2, offs, mids, 16, *[b[2].weight for b in branches], *[b[2].bias for b in branches])
             else:
-                feats = [b[1](z1[:, o:o + m]) for b, o, m in zip(branches, offs, mids)]
+                feats = [b[1](zj) for b, zj in zip(branches, ops.SplitChannelsFn.apply(z1, offs, mids))]
                 out = _proj([b[2] for b in branches], feats)
             o2o.append(out[:, : self.no])
             o2m.append(out[:, self.no:])

@@ -421,6 +421,37 @@ class FusedConvBNActFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------
+# channel slices of one map for several consumers
+# ------------------------------------------------------------------------------------------------------
+class SplitChannelsFn(torch.autograd.Function):
+    """x[:, o_j : o_j + m_j] for every j as strided views (no copy); the backward writes the consumers' gradients side by side into
+    ONE tensor.  Plain slicing makes autograd zero-fill a full-size tensor per slice and add them up pairwise: with the 16 branches
+    of a non-uniform head (M-3D: 128-channel cls next to 64-channel regression branches) that was 15 full-map adds per level."""
+
+    @staticmethod
+    def forward(ctx, x, offs, widths):
+        ctx.offs, ctx.widths, ctx.C = tuple(offs), tuple(widths), x.shape[1]
+        covered = sorted(zip(offs, widths))
+        ctx.dense = covered[0][0] == 0 and all(a + w == b for (a, w), (b, _) in zip(covered, covered[1:])) and covered[-1][0] + covered[-1][1] == x.shape[1]
+        ctx.order = [j for _, j in sorted((o, j) for j, o in enumerate(offs))]
+        return tuple(x[:, o:o + w] for o, w in zip(offs, widths))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        B, _, H, W = ref.shape
+        if ctx.dense and all(g is not None for g in grads):
+            parts = [to_nhwc(grads[j], ref.dtype, dense=True).permute(0, 2, 3, 1) for j in ctx.order]  # physical (B, H, W, c_j)
+            return torch.cat(parts, 3).permute(0, 3, 1, 2), None, None
+        dx = nhwc_empty(B, ctx.C, H, W, ref.dtype, ref.device)
+        dx.zero_()
+        for g, o, w in zip(grads, ctx.offs, ctx.widths):
+            if g is not None:
+                dx[:, o:o + w].add_(g)
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
 # plain nn.Conv2d(c, out, 1) with bias (head projections)
 # ------------------------------------------------------------------------------------------------------
 class HeadProjFn(torch.autograd.Function):
