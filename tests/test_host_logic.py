@@ -83,6 +83,36 @@ def test_postprocess_refuses_cpu_tensors():
         PL.v10_3Dpostprocess(g["preds"], 50, 3)
 
 
+def test_kitti_decode_and_optimizer_side_refuse_cpu_tensors():
+    """the eval tail and the optimizer-side kernels are HIP paths too: no CPU fallback"""
+    from yolov10_3d_amd import kitti, optim
+    g = load_golden("kitti_decode")
+    with pytest.raises(y3d.Y3DError):
+        kitti.decode_preds_eval(g["preds"], g["calib"], ["a", "b", "c"], g["ratio"], g["inv_trans"])
+    with pytest.raises(y3d.Y3DError):
+        kitti.decode_preds_device(torch.zeros(2, 5, 36), g["calib"][:2], g["ratio"][:2], None, undo_augment=False)  # not 37 columns
+    lin = torch.nn.Linear(4, 4)
+    lin.weight.grad, lin.bias.grad = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+    for opt in (optim.FusedSGD(list(lin.parameters())), optim.FusedAdamW(list(lin.parameters()))):
+        with pytest.raises(y3d.Y3DError):
+            opt.step()
+    with pytest.raises(y3d.Y3DError):
+        optim.ModelEMA(lin).update(lin)
+
+
+def test_build_optimizer_groups_follow_reference():
+    """engine/trainer.py:766-790: biases (no decay) | weights (decay) | normalisation weights (no decay); SGD nesterov or AdamW"""
+    from yolov10_3d_amd import optim
+    m = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml")
+    for name, cls in (("SGD", optim.FusedSGD), ("AdamW", optim.FusedAdamW)):
+        o = optim.build_optimizer(m, lr=0.01, momentum=0.9, decay=5e-4, name=name)
+        assert type(o) is cls and [g["weight_decay"] for g in o.param_groups] == [0.0, 5e-4, 0.0]
+        assert all(p.dim() == 1 for p in o.param_groups[0]["params"]) and all(p.dim() == 4 for p in o.param_groups[1]["params"])
+        assert sum(len(g["params"]) for g in o.param_groups) == len({id(p) for p in m.parameters()})
+    with pytest.raises(NotImplementedError):
+        optim.build_optimizer(m, name="RMSProp")
+
+
 def test_no_positive_zero_ties_in_fixtures():
     """The top-k tie rule (lowest index first) only differs from the reference's library-dependent order when an
     in-box anchor with a metric of exactly 0 is selected; the golden fixtures contain no such case."""
