@@ -766,6 +766,56 @@ def test_kitti_decode_vs_oracle_and_golden():
     torch.testing.assert_close(rows.cpu(), torch.from_numpy(r_ref), rtol=1e-6, atol=1e-6)
 
 
+def test_eval_after_more_training_sees_new_weights():
+    """train -> eval -> train -> eval: the eval path caches packed weights + folded BatchNorm per module; the optimizer, the EMA and
+    bn_finalize write through raw pointers (no torch version bump), so the cache must be invalidated by ops.PARAM_EPOCH"""
+    import copy
+    from yolov10_3d_amd.optim import ModelEMA, build_optimizer
+    from bench import synth_batch
+    y3d.set_compute_dtype(torch.float32)
+    try:
+        torch.manual_seed(0)
+        model = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml").to(DEV).train()
+        opt = build_optimizer(model, lr=0.05)
+        ema = ModelEMA(model, decay=0.5, tau=1)
+        batch = synth_batch(2, 256, 256, 1, DEV)  # 8x8 cells at the coarsest level: the sparse eval head needs >= 50 per level
+
+        def train_step():
+            model.train()
+            loss, _ = model(batch)
+            loss.backward()
+            opt.step(max_norm=10.0)
+            opt.zero_grad()
+            ema.update(model)
+
+        def evals():
+            model.eval()
+            with torch.no_grad():
+                a = model(batch["img"])["one2one"][0].clone()
+                b = ema.ema(batch["img"])["one2one"][0].clone()
+                fresh = copy.deepcopy(model)  # no caches: the ground truth for the current weights
+                fresh_ema = copy.deepcopy(ema.ema)
+                for m in list(fresh.modules()) + list(fresh_ema.modules()):
+                    m.__dict__.pop("_eval_cache", None)
+                    m.__dict__.pop("_stack_cache", None)
+                c = fresh(batch["img"])["one2one"][0]
+                d = fresh_ema(batch["img"])["one2one"][0]
+            return a, b, c, d
+
+        train_step()
+        a1, b1, c1, d1 = evals()
+        check(a1, c1, 1e-6, "eval vs uncached copy (1)")
+        check(b1, d1, 1e-6, "EMA eval vs uncached copy (1)")
+        train_step()
+        train_step()
+        a2, b2, c2, d2 = evals()
+        check(a2, c2, 1e-6, "eval vs uncached copy (2)")
+        check(b2, d2, 1e-6, "EMA eval vs uncached copy (2)")
+        assert rel_err(a2, a1) > 1e-4 and rel_err(b2, b1) > 1e-4, "the weights moved, the outputs must move"
+    finally:
+        y3d.set_compute_dtype(torch.bfloat16)
+
+
 def test_fused_adamw_matches_torch():
     """clip_grad_norm_(10) + AdamW(betas=(0.9, 0.999), per-group decay) vs torch.optim.AdamW, 4 steps (tolerance: torch's lerp /
     addcdiv kernels may contract to FMAs, ours are compiled with -ffp-contract=off)"""

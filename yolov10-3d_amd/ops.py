@@ -113,6 +113,15 @@ class KernelTimer:
 
 TIMER = None  # set by bench.py
 
+# Parameters, BatchNorm running statistics and EMA weights are written by HIP kernels through raw pointers, which torch's tensor
+# version counters do not see.  Every such writer bumps this epoch, and the eval-path cache of packed / folded weights keys on it.
+PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
 
 # ------------------------------------------------------------------------------------------------------
 # Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
@@ -186,7 +195,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         if not training and not res_mode:
             # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor; the packed
             # weights and the scale/shift pair are cached until a parameter / buffer is modified in place or re-pointed
-            key = (w32.data_ptr(), w32._version, g32.data_ptr(), g32._version, b32._version, rm.data_ptr(), rm._version, rv._version,
+            key = (PARAM_EPOCH, w32.data_ptr(), w32._version, g32.data_ptr(), g32._version, b32._version, rm.data_ptr(), rm._version, rv._version,
                    dtype, k, g, Cg_pad, Cout, float(eps))
             hit = cache.get(key) if cache is not None else None
             if hit is None:
@@ -209,6 +218,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                                     k, k, s, p, part.data_ptr() if training else None, st))
     stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
     if training:
+        bump_param_epoch()  # bn_finalize updates the running statistics in place
         L.bn_finalize(part.data_ptr(), nblk, Cout, M, g32.data_ptr(), b32.data_ptr(), eps, momentum, rm.data_ptr(), rv.data_ptr(),
                       stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
     else:

@@ -152,6 +152,7 @@ class FusedSGD:
             self.last_norm = st["norm_clip"]
         self._steps += 1
         self._update(L, st, clip, s)
+        ops.bump_param_epoch()  # the parameters changed behind torch's version counters
 
     def _update(self, L, st, clip, s):
         L.mt_sgd(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["sizes"].data_ptr(), st["lr"].data_ptr(),
@@ -252,6 +253,7 @@ class ModelEMA:
             tb["eptr"], tb["ekey"] = torch.tensor(ekey, dtype=torch.int64, device=dev), ekey
         if mkey != tb["mkey"]:
             tb["mptr"], tb["mkey"] = torch.tensor(mkey, dtype=torch.int64, device=dev), mkey
+        ops.bump_param_epoch()
         lib().mt_ema(tb["eptr"].data_ptr(), tb["mptr"].data_ptr(), tb["sizes"].data_ptr(), tb["reps"].data_ptr(), tb["ct"].data_ptr(),
                      tb["co"].data_ptr(), tb["n"], CHUNK, float(d), float(1 - d), ops.stream())
 
