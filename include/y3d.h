@@ -45,6 +45,10 @@ int y3d_device_info(char* name, int name_len, int* compute_units, int* lds_bytes
 int y3d_pack_weight_fwd(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int Cin_g_pad, int kh, int kw, void* stream);
 /* OIHW fp32 parameter -> [G][Cin_g][kh*kw][Cout_g] (row pitch y3d_conv_kpad(dtype, kh*kw*Cout_g)) for the data gradient */
 int y3d_pack_weight_dgrad(int dtype, const float* w_oihw, void* out, int Cout, int Cin_g, int groups, int kh, int kw, void* stream);
+/* the two packings above for MANY weights in one launch (once per step, after the optimizer): desc is a DEVICE array of 8 int64 per
+ * weight {src fp32 OIHW, dst, a, b, c, taps, Kpad, mode}; mode 0 = forward layout (a = Cout, b = Cin/g, c = padded Cin/g),
+ * mode 1 = data-gradient layout (a = groups, b = Cout/g, c = Cin/g); chunk tables as in the optimizer kernels below */
+int y3d_mt_pack_weights(int dtype, const int64_t* desc, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, void* stream);
 int y3d_conv_kpad(int dtype, int k_total);
 /* number of BatchNorm partial rows of the generic implicit-GEMM kernel: ceil(B*Ho*Wo / 128) */
 int y3d_conv_stat_blocks(int B, int Ho, int Wo);

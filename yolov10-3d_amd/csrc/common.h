@@ -61,9 +61,12 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
-__device__ __forceinline__ float silu_f(float u) { return u / (1.f + __expf(-u)); }
+// sigmoid through v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE `/` expands to ~10 VALU instructions (div_scale, rcp, four FMAs,
+// div_fmas, div_fixup), which made the BatchNorm + SiLU kernels VALU-bound next to their 2-3 streams of HBM traffic
+__device__ __forceinline__ float fast_sigmoid_f(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
+__device__ __forceinline__ float silu_f(float u) { return u * fast_sigmoid_f(u); }
 __device__ __forceinline__ float silu_grad_f(float u) {
-  float s = 1.f / (1.f + __expf(-u));
+  float s = fast_sigmoid_f(u);
   return s * (1.f + u * (1.f - s));
 }
 

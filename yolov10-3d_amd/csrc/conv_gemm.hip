@@ -564,6 +564,40 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__
   TT<T>::st(out + idx, v);
 }
 
+// Multi-tensor weight packing: every conv weight of the model, forward layout (mode 0: [Cout][taps][Cg_pad], as pack_w_fwd_kernel) or
+// data-gradient layout (mode 1: [G][Cg][taps][Cn], as pack_w_dgrad_kernel), in ONE launch per step instead of two tiny launches per
+// conv.  desc[t] = {src fp32 OIHW, dst, a, b, c, taps, Kpad, mode}: mode 0: a = Cout, b = Cg, c = Cg_pad; mode 1: a = G, b = Cn, c = Cg.
+template <typename T>
+__global__ __launch_bounds__(256) void mt_pack_w_kernel(const long* __restrict__ desc, const int* __restrict__ ctensor, const int* __restrict__ coff,
+                                                        int chunk) {
+  const long* d = desc + (long)ctensor[blockIdx.x] * 8;
+  const float* __restrict__ w = (const float*)d[0];
+  T* __restrict__ out = (T*)d[1];
+  const int a = (int)d[2], b = (int)d[3], c = (int)d[4], taps = (int)d[5], Kpad = (int)d[6], mode = (int)d[7];
+  const long n = mode == 0 ? (long)a * Kpad : (long)a * c * Kpad;
+  const long beg = (long)coff[blockIdx.x] * chunk;
+  const long end = beg + chunk < n ? beg + chunk : n;
+  for (long idx = beg + threadIdx.x; idx < end; idx += 256) {
+    const int k = (int)(idx % Kpad);
+    float v = 0.f;
+    if (mode == 0) {
+      const int co = (int)(idx / Kpad);
+      if (k < taps * c) {
+        const int tap = k / c, ci = k - tap * c;
+        if (ci < b) v = w[((long)co * b + ci) * taps + tap];
+      }
+    } else {
+      const int ci = (int)((idx / Kpad) % c);
+      const int g = (int)(idx / ((long)Kpad * c));
+      if (k < taps * b) {
+        const int tap = k / b, co = k - tap * b;
+        v = w[((long)(g * b + co) * c + ci) * taps + tap];
+      }
+    }
+    TT<T>::st(out + idx, v);
+  }
+}
+
 template <typename T, int MODE>
 int launch_conv_mode(ConvP p, hipStream_t st) {
   dim3 block(256);
@@ -819,6 +853,16 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
   Y3D_LAUNCH_CHECK();
   int cg_real = groups == 1 ? Cin_real : p.Cg;
   launch_wgrad_reduce(slab, grad_oihw, nsplit, Cout, kh * kw, p.Cg, cg_real, accumulate, st);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_mt_pack_weights(int dtype, const int64_t* desc, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "mt_pack_weights: bad dtype");
+  Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_pack_weights: empty chunk table");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(mt_pack_w_kernel<bf16_t>, dim3(nchunks), dim3(256), 0, st, (const long*)desc, chunk_tensor, chunk_off, chunk);
+  else hipLaunchKernelGGL(mt_pack_w_kernel<float>, dim3(nchunks), dim3(256), 0, st, (const long*)desc, chunk_tensor, chunk_off, chunk);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

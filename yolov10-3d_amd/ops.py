@@ -7,6 +7,8 @@ dtype (bf16 by default, fp32 for the parity mode).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import BF16, F32, Y3DError, lib
@@ -123,6 +125,96 @@ def bump_param_epoch():
     PARAM_EPOCH += 1
 
 
+WEIGHT_EPOCH = 0  # bumped by the raw-pointer writers of PARAMETERS only (optimizer step): the packed training weights key on it
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    bump_param_epoch()
+
+
+class _PackRegistry:
+    """Packed compute-dtype copies of the conv weights for the training step, refreshed by ONE multi-tensor launch per step
+    (`y3d_mt_pack_weights`) instead of one tiny launch per conv and direction (S-3D: 113 launches of ~5 us + their gaps).
+
+    A weight is identified by (address, geometry); its packed buffer is persistent.  The first lookup after the weights changed
+    (WEIGHT_EPOCH moved: the fused optimizer wrote them) repacks every registered weight from whatever its address holds now;
+    a weight changed through torch (in-place op: its `_version` moved) is repacked on its own; an unknown weight is packed on its
+    own and registered.  Entries that nobody looked up for a few epochs are dropped (re-pointed / freed parameters)."""
+
+    CHUNK = 16384
+    KEEP = 4
+
+    def __init__(self, mode):
+        self.mode, self.entries, self.epoch, self.tables = mode, {}, None, None
+
+    def _pack_one(self, e):
+        L, st = lib(), stream()
+        a, b, c, taps, kpad, dt = e["geo"]
+        if self.mode == 0:
+            k = int(round(taps ** 0.5))
+            L.pack_weight_fwd(dt, e["src"], e["dst"].data_ptr(), a, b, c, k, k, st)
+        else:
+            k = int(round(taps ** 0.5))
+            L.pack_weight_dgrad(dt, e["src"], e["dst"].data_ptr(), a * b, c, a, k, k, st)
+
+    def _pack_all(self, dt):
+        ents = [e for e in self.entries.values() if e["geo"][5] == dt]
+        if not ents:
+            return
+        dev = ents[0]["dst"].device
+        key = tuple(id(e) for e in ents)
+        if self.tables is None or self.tables[0] != (key, dt):
+            desc, ct, co = [], [], []
+            for t, e in enumerate(ents):
+                a, b, c, taps, kpad, _ = e["geo"]
+                n = a * kpad if self.mode == 0 else a * c * kpad
+                desc += [e["src"], e["dst"].data_ptr(), a, b, c, taps, kpad, self.mode]
+                for j in range((n + self.CHUNK - 1) // self.CHUNK):
+                    ct.append(t)
+                    co.append(j)
+            self.tables = ((key, dt), torch.tensor(desc, dtype=torch.int64, device=dev), torch.tensor(ct, dtype=torch.int32, device=dev),
+                           torch.tensor(co, dtype=torch.int32, device=dev), len(ct))
+        _, desc, ct, co, n = self.tables
+        lib().mt_pack_weights(dt, desc.data_ptr(), ct.data_ptr(), co.data_ptr(), n, self.CHUNK, stream())
+
+    def lookup(self, w32, src_ptr, geo, dtype):
+        """geo = (a, b, c, taps, Kpad, dt) as y3d_mt_pack_weights; src_ptr: address of the (sub)tensor to pack -> packed tensor"""
+        key = (src_ptr, geo)
+        e = self.entries.get(key)
+        now = (WEIGHT_EPOCH, geo[5])
+        if e is None:
+            a, b, c, taps, kpad, dt = geo
+            n = a * kpad if self.mode == 0 else a * c * kpad
+            # "keep": the registry re-reads `src` at every epoch, so the storage behind it must outlive the entry
+            e = {"src": src_ptr, "geo": geo, "dst": torch.empty(n, dtype=dtype, device=w32.device), "ver": w32._version, "seen": WEIGHT_EPOCH,
+                 "keep": w32}
+            self.entries[key] = e
+            self._pack_one(e)
+            return e["dst"]
+        e["seen"] = WEIGHT_EPOCH
+        if self.epoch != now:
+            self.epoch = now
+            stale = [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > self.KEEP]
+            for k in stale:
+                del self.entries[k]
+            self._pack_all(geo[5])
+            for v in self.entries.values():
+                if v["geo"][5] == geo[5]:
+                    v["ver"] = None  # refreshed from memory: whatever version the tensor has now is the packed one
+        if e["ver"] is None:
+            e["ver"] = w32._version
+        elif e["ver"] != w32._version:  # changed through torch since it was packed (load_state_dict, init, broadcast)
+            e["ver"] = w32._version
+            self._pack_one(e)
+        return e["dst"]
+
+
+PACK_FWD, PACK_DGRAD = _PackRegistry(0), _PackRegistry(1)
+PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv packing launches instead of the registry
+
+
 # ------------------------------------------------------------------------------------------------------
 # Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
 # ------------------------------------------------------------------------------------------------------
@@ -140,7 +232,7 @@ def _timed(key, launch):
         launch()
 
 
-def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True):
+def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True, pack_cache=True):
     """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs."""
     L = lib()
     _require_gpu(x)
@@ -161,7 +253,8 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
         wcol = torch.zeros(Cout, 32, dtype=torch.float32, device=dev)
         wcol[:, :27] = w32.detach().permute(0, 2, 3, 1).reshape(Cout, 27)  # column (r*3+q)*3+ci
-        z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache)
+        z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache,
+                                     pack_cache=False)  # wcol is a temporary
         return z, (cfg + ("stem",) if cfg is not None else None), saved
     dw = g > 1 and g == Cin and g == Cout
     # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
@@ -211,8 +304,11 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
             L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), int(act),
                                 y.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p, st)
             return y, None, None
-        wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
-        L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
+        if pack_cache and training and PACK_CACHE:
+            wp = PACK_FWD.lookup(w32, w32.data_ptr(), (Cout, Cin // g, Cg_pad, k * k, k * k * Cg_pad, dt), dtype)
+        else:
+            wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
+            L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
         _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
                lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
                                     k, k, s, p, part.data_ptr() if training else None, st))
@@ -304,8 +400,12 @@ def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
             assert g == 1 or (lo, hi) == (0, Cout)
             co = hi - lo
             kp = L.conv_kpad(dt, k * k * (co // g))
-            wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
-            L.pack_weight_dgrad(dt, w32.data_ptr() + lo * (Cin // g) * k * k * 4, wpd.data_ptr(), co, Cin // g, g, k, k, st)
+            src = w32.data_ptr() + lo * (Cin // g) * k * k * 4
+            if stem or not PACK_CACHE:
+                wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
+                L.pack_weight_dgrad(dt, src, wpd.data_ptr(), co, Cin // g, g, k, k, st)
+            else:
+                wpd = PACK_DGRAD.lookup(w32, src, (g, co // g, Cin // g, k * k, kp, dt), dtype)
             dx = nhwc_empty(B, Cin, H, W, dtype, dev)
             dsb, dsh, dsw = s3(dy)
             _timed(("conv_dgrad", dt, B, H, W, Cin, co, k, s, g),

@@ -152,7 +152,7 @@ class FusedSGD:
             self.last_norm = st["norm_clip"]
         self._steps += 1
         self._update(L, st, clip, s)
-        ops.bump_param_epoch()  # the parameters changed behind torch's version counters
+        ops.bump_weight_epoch()  # the parameters changed behind torch's version counters
 
     def _update(self, L, st, clip, s):
         L.mt_sgd(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["sizes"].data_ptr(), st["lr"].data_ptr(),
