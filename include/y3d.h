@@ -84,7 +84,8 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
 /* ------------------------------------------------------------------------------------------------
  * Depth-wise convolution (dwconv.hip) — Conv(g=c): conv.py:172-177, block.py:705-706,747-751,783,824
  * ---------------------------------------------------------------------------------------------- */
-int y3d_dw_blocks(int64_t M);  /* rows of BN partials / weight-gradient slabs for M output pixels */
+int y3d_dw_blocks(int64_t M);        /* rows of BN partials for M output pixels */
+int y3d_dw_wgrad_blocks(int64_t M);  /* weight-gradient slabs for M output pixels */
 int y3d_dw_pack_weight(const float* w_oihw, float* out_taps_c, int C, int kh, int kw, void* stream);
 int y3d_dwconv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
                      const float* w_packed, void* y, int64_t ysw, int Ho, int Wo, int kh, int kw, int stride, int pad,
@@ -92,7 +93,7 @@ int y3d_dwconv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t
 int y3d_dwconv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int C,
                           const float* w_packed, void* dx, int64_t xsw, int H, int W, int kh, int kw, int stride, int pad,
                           void* stream);
-/* slab: y3d_dw_blocks(B*Ho*Wo) * kh*kw*C floats */
+/* slab: y3d_dw_wgrad_blocks(B*Ho*Wo) * kh*kw*C floats */
 int y3d_dwconv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
                             const void* dy, int64_t dsw, int Ho, int Wo, int kh, int kw, int stride, int pad, float* slab,
                             float* grad_oihw, int accumulate, void* stream);

@@ -70,6 +70,21 @@ __device__ __forceinline__ float silu_grad_f(float u) {
   return s * (1.f + u * (1.f - s));
 }
 
+// v + v[lane ^ 16], v + v[lane ^ 32]: gfx950 row swaps on the VALU (v_permlane16_swap / v_permlane32_swap exchange the odd 16- / 32-lane
+// groups of one register with the even groups of the other), v + v[lane ^ 8]: a DPP rotate inside the 16-lane row.  No LDS crossbar
+// (ds_bpermute) traffic: the depth-wise weight-gradient epilogue folds 56 values per lane and was LDS-bound with shuffles.
+__device__ __forceinline__ float lane_xor8_sum(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+}
+__device__ __forceinline__ float lane_xor16_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_xor32_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the total.
 // Four v_add_f32 with DPP operand swizzles (quad_perm xor-1, xor-2, row_half_mirror, row_mirror) - no LDS crossbar round trips.
 __device__ __forceinline__ float wave_xor_sum16(float v) {

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
       for (int j = 0; j < CE; ++j) acc[j] = 0.f;
       const T* xb = X + (long)b * p.xsb + c;
       if (K > 0) {
-#pragma unroll
+        // K = 7: one filter row (7 loads) in flight at a time -- unrolled over all 49 taps the kernel needed 512 VGPRs and spilled
+#pragma unroll K == 3 ? 3 : 1
         for (int r = 0; r < K; ++r) {
           int hh;
           bool okh;
@@ -129,80 +130,136 @@ struct DwWP {
   long xsb, xsh, xsw, dsw;
   int B, H, W, Ho, Wo, C, kh, kw, stride, pad;
   long M;
-  int px_per_block;
+  int px_per_block, nblk, nslab;
 };
 
-template <typename T>
+// K = 3 / 7: filter width known at compile time; K = 0: any width up to 8.  A block owns ONE filter row of a 64-channel
+// slab over a pixel range: the small maps these layers run on (20x20 .. 80x80) need the parallelism -- walking the rows in passes
+// inside a block left the 7x7 layers latency-bound at 150 us for 13 MB.  Pixel coordinates advance incrementally (no divisions in
+// the loop), a row's loads are issued together (predicated) and two pixels are in flight per thread.
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWP p) {
   constexpr int CE = TT<T>::CE;
   constexpr int CT = 64 / CE;
   constexpr int PT = 256 / CT;
-  constexpr int TG = 9;  // taps per pass
-  __shared__ float sh[PT][64];
+  constexpr int RP = 1;                                // filter rows per block
+  constexpr int KW = K > 0 ? K : 8;                    // accumulator columns (K = 0: kw <= 8)
+  __shared__ float sh[4][RP * KW * 64];
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
-  const int cs = blockIdx.y * 64;
+  const int kh = K > 0 ? K : p.kh, kw = K > 0 ? K : p.kw;
+  // XCD-aware block order: workgroup L runs on XCD L % 8; within one XCD's stream the filter rows of a (pixel range, channel slab)
+  // tile are consecutive, so the kh blocks that read the same dy tile and overlapping x rows share that XCD's L2
+  const int L = blockIdx.x, jx = L >> 3;
+  const int row = jx % kh, tile = (jx / kh) * 8 + (L & 7);
+  if (tile >= p.nblk * p.nslab) return;
+  const int bx = tile % p.nblk;
+  const int cs = (tile / p.nblk) * 64;
   const int c = cs + ct * CE;
-  const int taps = p.kh * p.kw;
+  const int taps = kh * kw;
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ D = (const T*)p.dy;
-  long pbeg = (long)blockIdx.x * p.px_per_block;
-  long pend = pbeg + p.px_per_block < p.M ? pbeg + p.px_per_block : p.M;
+  const long pbeg = (long)bx * p.px_per_block;
+  const long pend = pbeg + p.px_per_block < p.M ? pbeg + p.px_per_block : p.M;
   const int HWo = p.Ho * p.Wo;
-  for (int t0 = 0; t0 < taps; t0 += TG) {
-    float acc[TG][CE];
+  {
+    const int r0 = row * RP;
+    float acc[RP][KW][CE];
 #pragma unroll
-    for (int t = 0; t < TG; ++t)
+    for (int r = 0; r < RP; ++r)
 #pragma unroll
-      for (int j = 0; j < CE; ++j) acc[t][j] = 0.f;
+      for (int q = 0; q < KW; ++q)
+#pragma unroll
+        for (int j = 0; j < CE; ++j) acc[r][q][j] = 0.f;
     if (c < p.C) {
-      for (long m = pbeg + pt; m < pend; m += PT) {
-        int b = (int)(m / HWo);
-        int rem = (int)(m - (long)b * HWo);
-        int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      long m = pbeg + pt;
+      int b = (int)(m / HWo);
+      int rem = (int)(m - (long)b * HWo);
+      int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      auto one = [&](const uint4& dv, int bb, int hh0, int ww0) {
         float d[CE];
-        Chunk<T>::unpack(*(const uint4*)(D + m * p.dsw + c), d);
-        const T* xb = X + (long)b * p.xsb + c;
+        Chunk<T>::unpack(dv, d);
+        const T* xb = X + (long)bb * p.xsb + c;
+        // all loads of the pass first (predicated, zero outside the map), then the FMAs: with the load inside the bounds test every
+        // tap waited for the previous one (the 7x7 layers spent 150 us on 13 MB)
+        uint4 raw[RP][KW];
 #pragma unroll
-        for (int t = 0; t < TG; ++t) {
-          int tap = t0 + t;
-          if (tap < taps) {
-            int r = tap / p.kw, q = tap - r * p.kw;
-            int hh = ho * p.stride - p.pad + r, ww = wo * p.stride - p.pad + q;
-            if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
-              float v[CE];
-              Chunk<T>::unpack(*(const uint4*)(xb + (long)hh * p.xsh + (long)ww * p.xsw), v);
+        for (int r = 0; r < RP; ++r) {
+          const int hh = hh0 + r0 + r;
+          const bool okh = r0 + r < kh && hh >= 0 && hh < p.H;
 #pragma unroll
-              for (int j = 0; j < CE; ++j) acc[t][j] += d[j] * v[j];
-            }
+          for (int q = 0; q < KW; ++q) {
+            const int ww = ww0 + q;
+            const bool ok = okh && q < kw && ww >= 0 && ww < p.W;
+            raw[r][q] = ok ? *(const uint4*)(xb + (long)hh * p.xsh + (long)ww * p.xsw) : make_uint4(0, 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int r = 0; r < RP; ++r)
+#pragma unroll
+          for (int q = 0; q < KW; ++q) {
+            float v[CE];
+            Chunk<T>::unpack(raw[r][q], v);
+#pragma unroll
+            for (int j = 0; j < CE; ++j) acc[r][q][j] += d[j] * v[j];
+          }
+      };
+      auto advance = [&]() {
+        wo += PT;
+        while (wo >= p.Wo) { wo -= p.Wo; ++ho; }
+        while (ho >= p.Ho) { ho -= p.Ho; ++b; }
+      };
+      for (; m + PT < pend; m += 2 * PT) {
+        const uint4 d0 = *(const uint4*)(D + m * p.dsw + c), d1 = *(const uint4*)(D + (m + PT) * p.dsw + c);
+        const int b0 = b, h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+        advance();
+        const int b1 = b, h1 = ho * p.stride - p.pad, w1 = wo * p.stride - p.pad;
+        advance();
+        one(d0, b0, h0, w0);
+        one(d1, b1, h1, w1);
       }
+      if (m < pend) one(*(const uint4*)(D + m * p.dsw + c), b, ho * p.stride - p.pad, wo * p.stride - p.pad);
     }
+    // fold the 32 pixel rows of the block: 8 of them sit in one wave (lanes 8 apart) -> shuffles; the 4 waves meet in LDS once per pass
+    // (the first version folded tap by tap through LDS: 2 barriers + a 32-step loop per tap, ~50 us of the 7x7 layers' 150)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < TG; ++t) {
-      if (t0 + t < taps) {  // uniform
+    for (int r = 0; r < RP; ++r)
 #pragma unroll
-        for (int j = 0; j < CE; ++j) sh[pt][ct * CE + j] = acc[t][j];
-        __syncthreads();
-        if (threadIdx.x < 64 && cs + threadIdx.x < p.C) {
-          float a = 0.f;
-          for (int r = 0; r < PT; ++r) a += sh[r][threadIdx.x];
-          p.slab[((long)blockIdx.x * taps + t0 + t) * p.C + cs + threadIdx.x] = a;
+      for (int q = 0; q < KW; ++q)
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+          float v = acc[r][q][j];
+          if (CT == 8) v = lane_xor8_sum(v);  // lane = (pixel row % (64 / CT)) * CT + channel chunk: fold the pixel rows of the wave
+          v = lane_xor32_sum(lane_xor16_sum(v));
+          if (lane < CT) sh[wave][(r * KW + q) * 64 + ct * CE + j] = v;
         }
-        __syncthreads();
-      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RP * KW * 64; i += 256) {
+      const int t = i >> 6, cc = i & 63;
+      const int r = t / KW, q = t - r * KW;
+      if (r0 + r < kh && q < kw && cs + cc < p.C)
+        p.slab[((long)bx * taps + (r0 + r) * kw + q) * p.C + cs + cc] = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
     }
   }
 }
 
-// slab[nblk][taps][C] -> grad OIHW [C][1][kh][kw]
-__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nblk, int taps, int C, int accumulate) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= taps * C) return;
-  int c = idx % C, t = idx / C;
+// slab[nblk][taps][C] -> grad OIHW [C][1][kh][kw]; 8 lanes share the block loop of an element and fold through LDS
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nblk, int taps, int C,
+                                                              int accumulate) {
+  __shared__ float sh[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + e;
+  const int n = taps * C;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += slab[(long)b * taps * C + idx];
-  long o = (long)c * taps + t;
+  if (idx < n)
+    for (int b = sl; b < nblk; b += 8) s += slab[(long)b * n + idx];
+  sh[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || idx >= n) return;
+#pragma unroll
+  for (int j = 1; j < 8; ++j) s += sh[j][e];
+  const int c = idx % C, t = idx / C;
+  const long o = (long)c * taps + t;
   grad[o] = accumulate ? grad[o] + s : s;
 }
 
@@ -217,9 +274,17 @@ __global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 
 extern "C" {
 
+// 64 pixels (two per thread) per block: the stencil loop is a chain of load rounds (one per filter row), so small maps need many
+// blocks to cover the latency -- with 256 pixels per block the 7x7 layers @20x20 ran 200 blocks on 256 CUs at 0.08 TB/s
 int y3d_dw_blocks(int64_t M) {
-  long n = (M + 255) / 256;
+  long n = (M + 63) / 64;
   return (int)(n < 1 ? 1 : (n > 2048 ? 2048 : n));
+}
+
+// weight gradient: every block ends with a slab of taps x C partial sums, so fewer, longer blocks
+int y3d_dw_wgrad_blocks(int64_t M) {
+  long n = (M + 127) / 128;
+  return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 
 int y3d_dw_pack_weight(const float* w_oihw, float* out, int C, int kh, int kw, void* stream) {
@@ -298,14 +363,22 @@ int y3d_dwconv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, 
   p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.dsw = dsw;
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.M = (long)B * Ho * Wo;
-  int nblk = y3d_dw_blocks(p.M);
+  int nblk = y3d_dw_wgrad_blocks(p.M);
   p.px_per_block = (int)((p.M + nblk - 1) / nblk);
-  dim3 grid(nblk, cdiv(C, 64));
+  p.nblk = nblk; p.nslab = cdiv(C, 64);
+  dim3 grid(cdiv(nblk * p.nslab, 8) * 8 * kh);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, grid, dim3(256), 0, st, p);
+  Y3D_CHECK(kw <= 8 || (kh == kw && (kh == 3 || kh == 7)), "dwconv2d_bwd_weight: kernels wider than 8 taps are not supported");
+#define Y3D_DWW(T)                                                                                                          \
+  do {                                                                                                                      \
+    if (kh == 3 && kw == 3) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 3>), grid, dim3(256), 0, st, p);                      \
+    else if (kh == 7 && kw == 7) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 7>), grid, dim3(256), 0, st, p);                 \
+    else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 0>), grid, dim3(256), 0, st, p);                                         \
+  } while (0)
+  if (dtype == Y3D_BF16) Y3D_DWW(bf16_t); else Y3D_DWW(float);
+#undef Y3D_DWW
   Y3D_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv((long)C * kh * kw, 256)), dim3(256), 0, st, slab, grad_oihw, nblk, kh * kw, C, accumulate);
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv((long)C * kh * kw, 32)), dim3(256), 0, st, slab, grad_oihw, nblk, kh * kw, C, accumulate);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

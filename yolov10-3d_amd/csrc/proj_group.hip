@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
   constexpr int CT = 64 / CE;
   constexpr int PT = 256 / CT;
   constexpr int OG = 8;  // outputs per pass over the pixel range (the 24-output heading branch: 3 passes)
-  __shared__ float sh[PT][64];
+  __shared__ float sh[4][OG * 64];
+  __shared__ float shb[4][OG];
   const int br = blockIdx.z, Cin = g.cin, Cout = g.cout[br];
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
   const int cs = blockIdx.y * 64;
@@ -174,30 +175,32 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
       }
       for (; px < pend; px += PT) one(*(const uint4*)(xp + px * xsw + c), dp + px * dsw + o0);
     }
+    // fold the block's 32 pixel rows: the 8 rows of a wave by VALU lane swaps (bf16 layout: lane = (row % 8) * 8 + chunk), the 4 waves
+    // through LDS once per pass (it was 2-4 barriers and a 32-step LDS loop per output)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // the previous pass's readers are done with sh
 #pragma unroll
     for (int o = 0; o < OG; ++o) {
-      if (o0 + o < Cout) {
 #pragma unroll
-        for (int j = 0; j < CE; ++j) sh[pt][ct * CE + j] = acc[o][j];
-        __syncthreads();
-        if (threadIdx.x < 64 && cs + threadIdx.x < Cin) {
-          float a = 0.f;
-          for (int r = 0; r < PT; ++r) a += sh[r][threadIdx.x];
-          slab[((long)blockIdx.x * ctot + g.ooff[br] + o0 + o) * Cin + cs + threadIdx.x] = a;
-        }
-        __syncthreads();
-        if (blockIdx.y == 0) {
-          sh[pt][ct] = bacc[o];
-          __syncthreads();
-          if (threadIdx.x == 0) {
-            float a = 0.f;
-            for (int r = 0; r < PT; ++r) a += sh[r][0];
-            bslab[(long)blockIdx.x * ctot + g.ooff[br] + o0 + o] = a;
-          }
-          __syncthreads();
-        }
+      for (int j = 0; j < CE; ++j) {
+        float v = acc[o][j];
+        if (CT == 8) v = lane_xor8_sum(v);
+        v = lane_xor32_sum(lane_xor16_sum(v));
+        if (lane < CT) sh[wave][o * 64 + ct * CE + j] = v;
       }
+      float bv = bacc[o];
+      if (CT == 8) bv = lane_xor8_sum(bv);
+      bv = lane_xor32_sum(lane_xor16_sum(bv));
+      if (lane == 0) shb[wave][o] = bv;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < OG * 64; i += 256) {
+      const int o = i >> 6, cc = i & 63;
+      if (o0 + o < Cout && cs + cc < Cin)
+        slab[((long)blockIdx.x * ctot + g.ooff[br] + o0 + o) * Cin + cs + cc] = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+    }
+    if (blockIdx.y == 0 && threadIdx.x < OG && o0 + threadIdx.x < Cout)
+      bslab[(long)blockIdx.x * ctot + g.ooff[br] + o0 + threadIdx.x] = shb[0][threadIdx.x] + shb[1][threadIdx.x] + shb[2][threadIdx.x] + shb[3][threadIdx.x];
   }
 }
 

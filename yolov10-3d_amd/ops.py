@@ -391,7 +391,7 @@ def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
             dx = nhwc_empty(B, Cin, H, W, dtype, dev)
             dsb, dsh, dsw = s3(dy)
             L.dwconv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wp.data_ptr(), dx.data_ptr(), Cin, H, W, k, k, s, p, st)
-        slab = _f32(L.dw_blocks(M) * k * k * Cout, dev)
+        slab = _f32(L.dw_wgrad_blocks(M) * k * k * Cout, dev)
         L.dwconv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, dy.data_ptr(), Cout, Ho, Wo, k, k, s, p, slab.data_ptr(),
                               dW.data_ptr(), 0, st)
     else:
