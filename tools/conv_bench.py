@@ -19,6 +19,8 @@ SHAPES = [  # B, H, W, Cin, Cout, k, s, g
     (32, 80, 80, 96, 96, 3, 1, 1),        # M-3D body (channel counts that are multiples of 32, not 64)
     (32, 40, 40, 192, 192, 3, 1, 1),
     (32, 160, 160, 48, 48, 3, 1, 1),
+    (32, 80, 80, 2048, 384, 1, 1, 16),    # the 16 head projections of a level as a grouped 1x1 conv padded to 24 outputs per branch
+    (32, 40, 40, 2048, 384, 1, 1, 16),
 ]
 
 def main():

@@ -30,6 +30,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void projg_fwd_kernel(ProjG g, const T* __restrict__ x, long xsw, T* __restrict__ y, long ysw, long P, BNP bn) {
   constexpr int CE = TT<T>::CE;
   constexpr int CN = 24;
+  constexpr int PXB = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sw = (float*)smem;             // [24][Cin]
   float* sbn = sw + 24 * g.cin;         // [2][Cin] scale, shift of this branch's channels
@@ -40,43 +41,46 @@ __global__ __launch_bounds__(256) void projg_fwd_kernel(ProjG g, const T* __rest
   __syncthreads();
   const int sub = threadIdx.x & 7;
   const int cpr = Cin / CE;
-  long px = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const T* xp = x + g.xoff[br];
-  float acc[CN];
+  // PXB pixels per thread (a block covers 32 * PXB pixels): the block's weight + BatchNorm slab is loaded once for all of them
+  for (int it = 0; it < PXB; ++it) {
+    const long px = ((long)blockIdx.x * PXB + it) * 32 + (threadIdx.x >> 3);
+    float acc[CN];
 #pragma unroll
-  for (int o = 0; o < CN; ++o) acc[o] = 0.f;
-  if (px < P) {
-    for (int ch = sub; ch < cpr; ch += 8) {
-      float v[CE];
-      Chunk<T>::unpack(*(const uint4*)(xp + px * xsw + ch * CE), v);
-      if (bn.scale) {
+    for (int o = 0; o < CN; ++o) acc[o] = 0.f;
+    if (px < P) {
+      for (int ch = sub; ch < cpr; ch += 8) {
+        float v[CE];
+        Chunk<T>::unpack(*(const uint4*)(xp + px * xsw + ch * CE), v);
+        if (bn.scale) {
 #pragma unroll
-        for (int j = 0; j < CE; ++j) {
-          float u = v[j] * sbn[ch * CE + j] + sbn[Cin + ch * CE + j];
-          v[j] = TT<T>::rnd(bn.act ? silu_f(u) : u);  // rounded as the materialised activation tensor would be
+          for (int j = 0; j < CE; ++j) {
+            float u = v[j] * sbn[ch * CE + j] + sbn[Cin + ch * CE + j];
+            v[j] = TT<T>::rnd(bn.act ? silu_f(u) : u);  // rounded as the materialised activation tensor would be
+          }
         }
+#pragma unroll
+        for (int o = 0; o < CN; ++o)
+          if (o < Cout) {
+            const float* wr = sw + o * Cin + ch * CE;
+#pragma unroll
+            for (int j = 0; j < CE; ++j) acc[o] += v[j] * wr[j];
+          }
       }
-#pragma unroll
-      for (int o = 0; o < CN; ++o)
-        if (o < Cout) {
-          const float* wr = sw + o * Cin + ch * CE;
-#pragma unroll
-          for (int j = 0; j < CE; ++j) acc[o] += v[j] * wr[j];
-        }
     }
-  }
-#pragma unroll
-  for (int o = 0; o < CN; ++o)
-    if (o < Cout) {  // uniform
-      acc[o] += __shfl_xor(acc[o], 1);
-      acc[o] += __shfl_xor(acc[o], 2);
-      acc[o] += __shfl_xor(acc[o], 4);
-    }
-  if (px < P && sub == 0) {
-    T* yp = y + px * ysw + g.ooff[br];
 #pragma unroll
     for (int o = 0; o < CN; ++o)
-      if (o < Cout) TT<T>::st(yp + o, acc[o] + g.b[br][o]);
+      if (o < Cout) {  // uniform
+        acc[o] += __shfl_xor(acc[o], 1);
+        acc[o] += __shfl_xor(acc[o], 2);
+        acc[o] += __shfl_xor(acc[o], 4);
+      }
+    if (px < P && sub == 0) {
+      T* yp = y + px * ysw + g.ooff[br];
+#pragma unroll
+      for (int o = 0; o < CN; ++o)
+        if (o < Cout) TT<T>::st(yp + o, acc[o] + g.b[br][o]);
+    }
   }
 }
 
@@ -145,7 +149,13 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
 #pragma unroll
         for (int j = 0; j < CE; ++j) { bsc[j] = bn.scale[g.xoff[br] + c + j]; bsh[j] = bn.shift[g.xoff[br] + c + j]; }
       }
-      auto one = [&](const uint4& xv, const T* drow) {
+      // dy values of one pixel for this pass (clamped index: lanes past the branch's last output re-read it, never past the row)
+      auto dload = [&](long px, float* d) {
+        const T* drow = dp + px * dsw + o0;
+#pragma unroll
+        for (int o = 0; o < OG; ++o) d[o] = TT<T>::ld(drow + (o < no ? o : no - 1));
+      };
+      auto one = [&](const uint4& xv, const float* d) {
         float v[CE];
         Chunk<T>::unpack(xv, v);
         if (bn.scale) {  // x is the pre-BatchNorm tensor: rebuild the activation the forward projected
@@ -158,22 +168,27 @@ __global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T*
 #pragma unroll
         for (int o = 0; o < OG; ++o)
           if (o < no) {
-            float d = TT<T>::ld(drow + o);
-            bacc[o] += d;
+            bacc[o] += d[o];
 #pragma unroll
-            for (int j = 0; j < CE; ++j) acc[o][j] += d * v[j];
+            for (int j = 0; j < CE; ++j) acc[o][j] += d[o] * v[j];
           }
       };
       long px = pbeg + pt;
-      for (; px + 3 * PT < pend; px += 4 * PT) {  // four pixels in flight: the loop is latency-bound otherwise (1.2 TB/s)
+      for (; px + 3 * PT < pend; px += 4 * PT) {  // four pixels in flight, x chunks AND dy values: the loop is latency-bound otherwise
         const uint4 x0 = *(const uint4*)(xp + px * xsw + c), x1 = *(const uint4*)(xp + (px + PT) * xsw + c);
         const uint4 x2 = *(const uint4*)(xp + (px + 2 * PT) * xsw + c), x3 = *(const uint4*)(xp + (px + 3 * PT) * xsw + c);
-        one(x0, dp + px * dsw + o0);
-        one(x1, dp + (px + PT) * dsw + o0);
-        one(x2, dp + (px + 2 * PT) * dsw + o0);
-        one(x3, dp + (px + 3 * PT) * dsw + o0);
+        float d0[OG], d1[OG], d2[OG], d3[OG];
+        dload(px, d0); dload(px + PT, d1); dload(px + 2 * PT, d2); dload(px + 3 * PT, d3);
+        one(x0, d0);
+        one(x1, d1);
+        one(x2, d2);
+        one(x3, d3);
       }
-      for (; px < pend; px += PT) one(*(const uint4*)(xp + px * xsw + c), dp + px * dsw + o0);
+      for (; px < pend; px += PT) {
+        float d0[OG];
+        dload(px, d0);
+        one(*(const uint4*)(xp + px * xsw + c), d0);
+      }
     }
     // fold the block's 32 pixel rows: the 8 rows of a wave by VALU lane swaps (bf16 layout: lane = (row % 8) * 8 + chunk), the 4 waves
     // through LDS once per pass (it was 2-4 barriers and a 32-step LDS loop per output)
@@ -251,7 +266,7 @@ static int proj_group_fwd_impl(int dtype, int nb, int cin, const void* x, int64_
   if (ctot < 0) return ctot;
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "proj_group_fwd: bad dtype");
   Y3D_CHECK(cin % (dtype == Y3D_BF16 ? 8 : 4) == 0 && ysw >= ctot, "proj_group_fwd: channel alignment");
-  dim3 grid(cdiv(P, 32), 1, nb);
+  dim3 grid(cdiv(P, 32 * 4), 1, nb);  // PXB = 4 pixels per thread
   size_t sm = (size_t)26 * cin * 4;
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_fwd_kernel<bf16_t>, grid, dim3(256), sm, (hipStream_t)stream, g, (const bf16_t*)x, (long)xsw, (bf16_t*)y, (long)ysw, (long)P, bn);
   else hipLaunchKernelGGL(projg_fwd_kernel<float>, grid, dim3(256), sm, (hipStream_t)stream, g, (const float*)x, (long)xsw, (float*)y, (long)ysw, (long)P, bn);
