@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void projg_bwd_data_kernel(ProjG g, const T* _
 
 // slab[blk][ooff + co][ci] / bslab[blk][ooff + co]: per-block partial sums over the block's pixel range
 template <typename T>
-__global__ __launch_bounds__(256) void projg_bwd_weight_kernel(ProjG g, const T* __restrict__ x, long xsw, const T* __restrict__ dy, long dsw,
+__global__ __launch_bounds__(256, 2) void projg_bwd_weight_kernel(ProjG g, const T* __restrict__ x, long xsw, const T* __restrict__ dy, long dsw,
                                                                float* __restrict__ slab, float* __restrict__ bslab, long P, int ctot,
                                                                int px_per_block, BNP bn) {
   constexpr int CE = TT<T>::CE;
