@@ -18,6 +18,7 @@
 //
 // The data gradient of such a conv is the same kernel on dy with the taps flipped (`flip`).
 #include "common.h"
+#include <cstdlib>
 #include "conv_frag.h"
 
 namespace {
@@ -341,6 +342,15 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
   p.ntx = cdiv(W, 16); p.nty = H / th; p.ntc = cdiv(Cn, 128); p.flip = flip;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == Y3D_BF16) return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
+  if (dtype == Y3D_BF16) {
+    // the persistent kernel runs one 512-pixel tile per CU at a time: with fewer tiles than half the CUs (128 -> 128 @40x40, B = 32:
+    // 120) the 256-pixel tiles of this file's kernel fill the chip better (628 / 671 against 448 / 482 TFLOP/s forward / dgrad)
+    static int v2max = -1;
+    if (v2max < 0) { const char* e = getenv("Y3D_V2_MAX_TILES"); v2max = e ? atoi(e) : 129; }
+    const long wide_tiles = (long)G * cdiv(B, 32 / th) * p.nty * p.ntx * p.ntc;
+    if (wide_tiles < v2max && Cg % 64 == 0)  // this kernel's K slab is a 128-byte row: 64 bf16 channels
+      return th == 16 ? launch_tile_epi<bf16_t, 16>(p, st) : launch_tile_epi<bf16_t, 8>(p, st);
+    return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
+  }
   return th == 16 ? launch_tile_epi<float, 16>(p, st) : launch_tile_epi<float, 8>(p, st);
 }
