@@ -507,8 +507,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   long idx = (long)blockIdx.x * EPB + e;
   long n = (long)Ctot * taps * Cg;
   float s = 0.f;
-  if (idx < n)
-    for (int k = sl; k < nsplit; k += SL) s += slab[(long)k * n + idx];
+  if (idx < n) {
+    // four slabs in flight per lane (the partial sums keep a fixed order: bitwise reproducible)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = sl;
+    for (; k + 3 * SL < nsplit; k += 4 * SL) {
+      s0 += slab[(long)k * n + idx];
+      s1 += slab[(long)(k + SL) * n + idx];
+      s2 += slab[(long)(k + 2 * SL) * n + idx];
+      s3 += slab[(long)(k + 3 * SL) * n + idx];
+    }
+    for (; k < nsplit; k += SL) s0 += slab[(long)k * n + idx];
+    s = (s0 + s1) + (s2 + s3);
+  }
   if (SL > 1) {
     sh[sl][e] = s;
     __syncthreads();
@@ -527,7 +538,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 inline void launch_wgrad_reduce(const float* slab, float* grad, int nsplit, int Ctot, int taps, int Cg, int Cg_real, int accumulate, hipStream_t st) {
   long n = (long)Ctot * taps * Cg;
+  // split lanes per element: enough loads in flight for the slab stream (nsplit x n floats) whatever the layer's shape
   if (n <= 65536 && nsplit >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 16)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  else if (n <= 1048576 && nsplit >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(cdiv(n, 32)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  else if (nsplit >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(cdiv(n, 128)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
   else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
 }
 
