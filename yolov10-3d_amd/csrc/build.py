@@ -28,7 +28,7 @@ def needs(src, obj, deps):
 def compile_one(name, force):
     src = os.path.join(HERE, name)
     obj = os.path.join(OBJ, name + ".o")
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "y3d.h")]
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")] + [os.path.join(HERE, "..", "..", "include", "y3d.h")]
     if force or needs(src, obj, deps):
         cmd = ["hipcc", "-x", "hip", *FLAGS, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -178,10 +178,19 @@ __global__ __launch_bounds__(256) void scores_kernel(const unsigned char* __rest
 }
 
 // scal[0] = max(sum target_scores, 1), scal[1] = n_fg
-__global__ void scal_kernel(const float* __restrict__ part, int nblk, float* __restrict__ scal) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < nblk; ++i) { a += part[i * 2]; b += part[i * 2 + 1]; }
+__global__ __launch_bounds__(64) void scal_kernel(const float* __restrict__ part, int nblk, float* __restrict__ scal) {
+  // one wave: 64 lanes stride over the block partials in fp64, folded through LDS in a fixed order (it was one thread: 74 us)
+  __shared__ double sh[64][2];
+  const int t = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int i = t; i < nblk; i += 64) { a += part[i * 2]; b += part[i * 2 + 1]; }
+  sh[t][0] = a;
+  sh[t][1] = b;
+  __syncthreads();
+  if (t == 0) {
+    a = 0.0; b = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) { a += sh[k][0]; b += sh[k][1]; }
     scal[0] = (float)(a > 1.0 ? a : 1.0);
     scal[1] = (float)b;
   }
