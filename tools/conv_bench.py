@@ -21,6 +21,8 @@ SHAPES = [  # B, H, W, Cin, Cout, k, s, g
     (32, 160, 160, 48, 48, 3, 1, 1),
     (32, 80, 80, 2048, 384, 1, 1, 16),    # the 16 head projections of a level as a grouped 1x1 conv padded to 24 outputs per branch
     (32, 40, 40, 2048, 384, 1, 1, 16),
+    (32, 320, 320, 32, 64, 3, 2, 1),      # first backbone downsample: narrow stride-2 (the data gradient is latency-bound)
+    (32, 160, 160, 64, 128, 3, 2, 1),
 ]
 
 def main():
