@@ -46,6 +46,11 @@ __device__ __forceinline__ void lds_wait(s16x4_t& a, s16x4_t& b, s16x4_t& c, s16
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+template <int N>
+__device__ __forceinline__ void lds_wait8(s16x4_t& a, s16x4_t& b, s16x4_t& c, s16x4_t& d, s16x4_t& e, s16x4_t& f, s16x4_t& g, s16x4_t& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N));
+}
+
 template <int TH>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
   typedef bf16_t T;
@@ -151,43 +156,49 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
           va[mt][hi] = ds_tr16(a);
         }
       }
-      // software pipeline over the taps: tap t+1's four fragment reads are issued before tap t's are awaited
-      s16x4_t vb[2][2][2];
-      auto issue_b = [&](int tap, int buf) {
-        const int r = tap / 3, q = tap % 3;
+      // The loop is LDS-read bound (a wave's 32 x 32 output tile reuses an x fragment for only two MFMAs), so the x rows are read
+      // ONCE per column shift q and shared by the three filter rows: tap (r, q) pairs halo rows (2ks + r, 2ks + r + 1), i.e. rows
+      // R0..R3 serve r = 0, 1, 2 as (R0,R1), (R1,R2), (R2,R3) -- 8 transposed reads per q instead of 12 (28 per K chunk instead of 40).
+      // Software pipeline over q: the next shift's eight reads are issued before the current one's are awaited.
+      s16x4_t vr[2][2][4];
+      auto issue_q = [&](int q, int buf) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int j0 = wj * 32 + nt * 16;
           const int cch = (j0 >> 3) + (pp4 >> 1);
 #pragma unroll
-          for (int hi = 0; hi < 2; ++hi) {
-            const int P = (2 * ks + hi + r) * HWD + 4 * grp + qq + q;  // halo pixel
+          for (int R = 0; R < 4; ++R) {
+            const int P = (2 * ks + R) * HWD + 4 * grp + qq + q;  // halo pixel
             const char* a = hb + P * 128 + ((cch ^ (((P >> 1) & 3) << 1)) << 4) + (pp4 & 1) * 8;
-            vb[buf][nt][hi] = ds_tr16(a);
+            vr[buf][nt][R] = ds_tr16(a);
           }
         }
       };
-      issue_b(0, 0);
-      lds_wait<4>(va[0][0], va[0][1], va[1][0], va[1][1]);
+      issue_q(0, 0);
+      lds_wait<8>(va[0][0], va[0][1], va[1][0], va[1][1]);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(va[mt][0], va[mt][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int cb = tap & 1;
-        if (tap < 8) {
-          issue_b(tap + 1, cb ^ 1);
-          lds_wait<4>(vb[cb][0][0], vb[cb][0][1], vb[cb][1][0], vb[cb][1][1]);
+      for (int q = 0; q < 3; ++q) {
+        const int cb = q & 1;
+        if (q < 2) {
+          issue_q(q + 1, cb ^ 1);
+          lds_wait8<8>(vr[cb][0][0], vr[cb][0][1], vr[cb][0][2], vr[cb][0][3], vr[cb][1][0], vr[cb][1][1], vr[cb][1][2], vr[cb][1][3]);
         } else {
-          lds_wait<0>(vb[cb][0][0], vb[cb][0][1], vb[cb][1][0], vb[cb][1][1]);
+          lds_wait8<0>(vr[cb][0][0], vr[cb][0][1], vr[cb][0][2], vr[cb][0][3], vr[cb][1][0], vr[cb][1][1], vr[cb][1][2], vr[cb][1][3]);
         }
-        bf16x8_t fb[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(vb[cb][nt][0], vb[cb][nt][1], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int r = 0; r < 3; ++r) {
+          bf16x8_t fb[2];
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            acc[tap][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[tap][mt][nt], 0, 0, 0);
+            fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(vr[cb][nt][r], vr[cb][nt][r + 1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[r * 3 + q][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[r * 3 + q][mt][nt], 0, 0, 0);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
