@@ -34,9 +34,14 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // (`s_waitcnt vmcnt(0)` before the first read of each K step), i.e. the next tile's DMA could never overlap this tile's MFMAs.
 // The asm form is invisible to that dependency tracking; the DMA'd buffer is only read after the kernel's own vmcnt(0) + barrier.
 // The result is not tracked either: `lds_wait` (below) must sit between the reads and their first use.
-__device__ __forceinline__ s16x4_t ds_tr16(const char* a) {
+template <int OFF>  // OFF: immediate byte offset (the row stride multiples of the fragment loop: no VALU address math per read)
+__device__ __forceinline__ s16x4_t ds_tr16(unsigned a) {
   s16x4_t v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)a));
+#ifdef Y3D_WGP_NOLDS
+  asm volatile("" : "=v"(v) : "v"(a));
+  return v;
+#endif
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
   return v;
 }
 // waits for every LDS read issued so far; the fragments are in/out operands so that their uses stay behind the wait
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
     int P = chunk >> 3, s = chunk & 7;
     h_y[rd] = chunk < HCH ? P / HWD : -100000;
     h_x[rd] = P - (P / HWD) * HWD;
-    h_c[rd] = (s ^ (((P >> 1) & 3) << 1)) * 8;
+    h_c[rd] = (s ^ (((h_x[rd] >> 1) & 3) << 1)) * 8;  // swizzle by the pixel's x inside the halo row: the same for every row
   }
   auto issue = [&](int tile, int buf) {
     int tx = tile % p.ntx;
@@ -105,8 +110,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
       int xx = x0 + d_px[rd];
       bool ok = xx < p.W && c0 + d_c[rd] < p.Cn;
       const T* src = ok ? D + (((long)b * p.H + y0 + d_row[rd]) * p.W + xx) * p.dsw + (long)g * p.Cn + c0 + d_c[rd] : zero;
+#ifndef Y3D_WGP_NODMA
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(db + (rd * NT + wave * 64) * 16), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(src));
+#endif
     }
 #pragma unroll
     for (int rd = 0; rd < HR; ++rd) {
@@ -114,8 +123,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
         int yy = y0 + h_y[rd] - 1, xx = x0 + h_x[rd] - 1;
         bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && ci0 + h_c[rd] < p.Cg;  // Cg % 64 == 32: the last slab is half zeros
         const T* src = ok ? X + (long)b * p.xsb + (long)yy * p.xsh + (long)xx * p.xsw + (long)g * p.Cg + ci0 + h_c[rd] : zero;
+#ifndef Y3D_WGP_NODMA
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(hb + (rd * NT + wave * 64) * 16), 16, 0, 0);
+#else
+        asm volatile("" ::"v"(src));
+#endif
       }
     }
   };
@@ -132,29 +145,46 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
   const int t_end = min(p.ntiles, t_beg + p.tiles_per_split);
   const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
 
+  // per-lane LDS byte offsets of the fragment reads, computed ONCE: with them recomputed per read (~9 integer ops x 28 reads per K
+  // chunk and wave) the loop was VALU-bound behind its own address arithmetic (ablation: no reads + no addresses = +25 %).
+  // dy tile: pixel (2ks + hi) * 16 + 4 grp + qq -> (2ks + hi) * 4096 + aoff[mt]; the swizzle only sees the pixel's low three bits.
+  // halo:    pixel (2ks + R) * 18 + x, x = 4 grp + qq + q -> (2ks + R) * 2304 + boff[q][nt]; the swizzle only sees x.
+  unsigned aoff[2], boff[3][2];
+  {
+    const int px8 = 4 * grp + qq;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int cch = ((wi * 32 + mt * 16) >> 3) + (pp4 >> 1);
+      aoff[mt] = px8 * 256 + ((cch ^ ((px8 & 7) << 1)) << 4) + (pp4 & 1) * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int x = px8 + q;
+        const int cch = ((wj * 32 + nt * 16) >> 3) + (pp4 >> 1);
+        boff[q][nt] = x * 128 + ((cch ^ (((x >> 1) & 3) << 1)) << 4) + (pp4 & 1) * 8;
+      }
+  }
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+
   if (t_beg < t_end) issue(t_beg, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int cur = (tile - t_beg) & 1;
     if (tile + 1 < t_end) issue(tile + 1, cur ^ 1);
-    const char* db = smem + cur * SBYTES;
-    const char* hb = db + DBYTES;
 #pragma unroll 1
-    for (int ks = 0; ks < NPX / 32; ++ks) {  // not unrolled: 40 LDS addresses per iteration are recomputed, not kept live
+    for (int ks = 0; ks < NPX / 32; ++ks) {
       // MFMA k = 8*grp + j  <->  pixel (row 2*ks + (j>>2), x 4*grp + (j&3)): a 32-lane half reads 8 consecutive pixels per instruction
       bf16x8_t fa[2];
       s16x4_t va[2][2];
+      const unsigned dks = smem_base + cur * SBYTES + ks * 8192;               // dy rows 2ks, 2ks + 1
+      const unsigned hks = smem_base + cur * SBYTES + DBYTES + ks * (2 * HWD * 128);  // halo rows 2ks ..
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int i0 = wi * 32 + mt * 16;
-        const int cch = (i0 >> 3) + (pp4 >> 1);
-#pragma unroll
-        for (int hi = 0; hi < 2; ++hi) {
-          const int prow = (2 * ks + hi) * 16 + 4 * grp + qq;  // pixel index inside the tile
-          const char* a = db + prow * 256 + ((cch ^ ((prow & 7) << 1)) << 4) + (pp4 & 1) * 8;
-          va[mt][hi] = ds_tr16(a);
-        }
+        va[mt][0] = ds_tr16<0>(dks + aoff[mt]);
+        va[mt][1] = ds_tr16<4096>(dks + aoff[mt]);
       }
       // The loop is LDS-read bound (a wave's 32 x 32 output tile reuses an x fragment for only two MFMAs), so the x rows are read
       // ONCE per column shift q and shared by the three filter rows: tap (r, q) pairs halo rows (2ks + r, 2ks + r + 1), i.e. rows
@@ -164,14 +194,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
       auto issue_q = [&](int q, int buf) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const int j0 = wj * 32 + nt * 16;
-          const int cch = (j0 >> 3) + (pp4 >> 1);
-#pragma unroll
-          for (int R = 0; R < 4; ++R) {
-            const int P = (2 * ks + R) * HWD + 4 * grp + qq + q;  // halo pixel
-            const char* a = hb + P * 128 + ((cch ^ (((P >> 1) & 3) << 1)) << 4) + (pp4 & 1) * 8;
-            vr[buf][nt][R] = ds_tr16(a);
-          }
+          const unsigned a = hks + boff[q][nt];
+          vr[buf][nt][0] = ds_tr16<0>(a);
+          vr[buf][nt][1] = ds_tr16<HWD * 128>(a);
+          vr[buf][nt][2] = ds_tr16<2 * HWD * 128>(a);
+          vr[buf][nt][3] = ds_tr16<3 * HWD * 128>(a);
         }
       };
       issue_q(0, 0);
@@ -197,7 +224,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
+#ifndef Y3D_WGP_NOMFMA
               acc[r * 3 + q][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[r * 3 + q][mt][nt], 0, 0, 0);
+#else
+              asm volatile("" ::"v"(fa[mt]), "v"(fb[nt]));
+#endif
         }
       }
     }
