@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_tile_kernel(WG3P p) {
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int cur = (tile - t_beg) & 1;
     if (tile + 1 < t_end) issue(tile + 1, cur ^ 1);
-#pragma unroll 1
+#pragma unroll  // the addresses are immediates now: unrolled, the next K chunk's reads overlap this one's MFMAs (+3 %)
     for (int ks = 0; ks < NPX / 32; ++ks) {
       // MFMA k = 8*grp + j  <->  pixel (row 2*ks + (j>>2), x 4*grp + (j&3)): a 32-lane half reads 8 consecutive pixels per instruction
       bf16x8_t fa[2];
