@@ -38,5 +38,12 @@ for (P, C) in [(32 * 80 * 80, 2048), (32 * 40 * 40, 2048), (32 * 160 * 160, 64),
                                             part.data_ptr(), P, C, st))
     t3 = timeit(lambda: L.bn_act_bwd_apply(1, y.data_ptr(), C, dz.data_ptr(), C, None, 0, f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), f[3].data_ptr(),
                                            f[4].data_ptr(), f[5].data_ptr(), 1, 0, 1, dy.data_ptr(), C, None, 0, P, C, st))
+    # the same kernels without the activation (act = 0): how much of the time is SiLU arithmetic rather than HBM traffic
+    u = timeit(lambda: L.bn_act_fwd(1, y.data_ptr(), C, f[0].data_ptr(), f[1].data_ptr(), 0, 0, None, 0, z.data_ptr(), C, P, C, st))
+    u2 = timeit(lambda: L.bn_act_bwd_reduce(1, y.data_ptr(), C, dz.data_ptr(), C, None, 0, f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), f[3].data_ptr(), 0, 0,
+                                            part.data_ptr(), P, C, st))
+    u3 = timeit(lambda: L.bn_act_bwd_apply(1, y.data_ptr(), C, dz.data_ptr(), C, None, 0, f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), f[3].data_ptr(),
+                                           f[4].data_ptr(), f[5].data_ptr(), 0, 0, 1, dy.data_ptr(), C, None, 0, P, C, st))
+    print(f"   no-act: fwd {u * 1e3:7.1f} us | bwd_reduce {u2 * 1e3:7.1f} us | bwd_apply {u3 * 1e3:7.1f} us")
     print(f"P={P:7d} C={C:5d} ({eb * 1e3:7.1f} MB/tensor): fwd {t * 1e3:7.1f} us {2 * eb / t * 1e3:7.0f} GB/s | bwd_reduce {t2 * 1e3:7.1f} us {2 * eb / t2 * 1e3:7.0f} GB/s | "
           f"bwd_apply {t3 * 1e3:7.1f} us {3 * eb / t3 * 1e3:7.0f} GB/s", flush=True)
