@@ -585,13 +585,26 @@ class HeadProjFn(torch.autograd.Function):
         w32 = [w.detach().float().contiguous() for w in ws]
         b32 = [b.detach().float().contiguous() for b in bs]
         off = 0
+        wide = []
         for x, w, b, co in zip(xs, w32, b32, couts):
-            for o0 in range(0, co, 24):
-                oc = min(24, co - o0)
-                L.proj_fwd(dt, x.data_ptr(), x.stride(3), w.data_ptr() + o0 * w.shape[1] * 4, b.data_ptr() + o0 * 4,
-                           out.data_ptr() + (off + o0) * esz, tot, P, x.shape[1], oc, st)
+            Cin = x.shape[1]
+            # wide projections (the 2D head's 64 box-distribution and nc class outputs): a 1x1 conv with bias on the MFMA kernels,
+            # written into its channel slice of `out`; the VALU kernel below is for the 3D head's 1..24 outputs per branch
+            mf = co >= 32 and co % 8 == 0 and off % 8 == 0 and tot % 8 == 0 and Cin % 8 == 0
+            wide.append(mf)
+            if mf:
+                wp = torch.empty(co * Cin, dtype=dtype, device=x.device)
+                L.pack_weight_fwd(dt, w.data_ptr(), wp.data_ptr(), co, Cin, Cin, 1, 1, st)
+                sb, sh, sw = s3(x)
+                L.conv2d_fwd(dt, x.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), b.data_ptr(), out.data_ptr() + off * esz, tot, H, W, co,
+                             1, 1, 1, 1, 0, None, st)
+            else:
+                for o0 in range(0, co, 24):
+                    oc = min(24, co - o0)
+                    L.proj_fwd(dt, x.data_ptr(), x.stride(3), w.data_ptr() + o0 * w.shape[1] * 4, b.data_ptr() + o0 * 4,
+                               out.data_ptr() + (off + o0) * esz, tot, P, x.shape[1], oc, st)
             off += co
-        ctx.n, ctx.couts, ctx.dtype = n, couts, dtype
+        ctx.n, ctx.couts, ctx.dtype, ctx.wide = n, couts, dtype, wide
         ctx.save_for_backward(*xs, *w32)
         return out
 
@@ -615,6 +628,31 @@ class HeadProjFn(torch.autograd.Function):
         for j, (x, w, co) in enumerate(zip(xs, ws, couts)):
             Cin = x.shape[1]
             dx = None
+            if ctx.wide[j]:
+                dptr = dout.data_ptr() + off * esz
+                dsb, dsh, _ = s3(dout)
+                if ctx.needs_input_grad[1 + j]:
+                    kp = L.conv_kpad(dt, co)
+                    wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
+                    L.pack_weight_dgrad(dt, w.data_ptr(), wpd.data_ptr(), co, Cin, 1, 1, 1, st)
+                    dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+                    L.conv2d_bwd_data(dt, dptr, dsb, dsh, dsw, B, H, W, co, wpd.data_ptr(), dx.data_ptr(), Cin, H, W, Cin, 1, 1, 1, 1, 0, st)
+                sb, sh, sw = s3(x)
+                ns = L.conv2d_wgrad_plan(dt, B, H, W, Cin, co, 1, 1, 1, 1, 0)
+                slab = _f32(ns * co * Cin, dev)
+                dW = torch.empty_like(w)
+                L.conv2d_bwd_weight(dt, x.data_ptr(), sb, sh, sw, B, H, W, Cin, Cin, dptr, dsw, H, W, co, 1, 1, 1, 1, 0, slab.data_ptr(), ns,
+                                    dW.data_ptr(), 0, st)
+                nbb = L.bn_bwd_blocks(P, co)  # bias gradient: column sums of the dout slice
+                part = _f32(nbb * co * 2, dev)
+                L.colsum_partials(dt, dptr, dsw, part.data_ptr(), P, co, st)
+                db, scratch = _f32(co, dev), _f32(2 * co, dev)
+                L.bn_bwd_finalize(part.data_ptr(), nbb, co, P, None, db.data_ptr(), 0, scratch.data_ptr(), scratch.data_ptr() + 4 * co, st)
+                dxs.append(dx)
+                dws.append(dW)
+                dbs.append(db)
+                off += co
+                continue
             if ctx.needs_input_grad[1 + j]:
                 dx = nhwc_empty(B, Cin, H, W, dtype, dev)
                 first = True
