@@ -11,6 +11,7 @@ namespace {
 
 // block-wide arg-max of (value desc, index asc) over `n` LDS values, K times, excluding earlier winners by overwriting them
 __device__ void block_topk(float* vals, int n, int K, int* out_idx, float* out_val, float* sv, int* si) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int j = 0; j < K; ++j) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -18,22 +19,21 @@ __device__ void block_topk(float* vals, int n, int K, int* out_idx, float* out_v
       float v = vals[a];
       if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
     }
-    sv[threadIdx.x] = bv;
-    si[threadIdx.x] = bi;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        float v2 = sv[threadIdx.x + s];
-        int i2 = si[threadIdx.x + s];
-        if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
-      }
-      __syncthreads();
+    // arg-max inside the wave by shuffles, across the (<= 16) waves through LDS: two barriers per winner instead of nine
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float v2 = __shfl_xor(bv, off);
+      const int i2 = __shfl_xor(bi, off);
+      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
     }
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-      int w = si[0];
-      out_idx[j] = w < n ? w : 0;
-      if (out_val) out_val[j] = sv[0];
-      if (w < n) vals[w] = -INFINITY;  // -inf entries can only be re-selected when fewer than K finite values exist
+      for (int w = 1; w < nw; ++w)
+        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+      out_idx[j] = bi < n ? bi : 0;
+      if (out_val) out_val[j] = bv;
+      if (bi < n) vals[bi] = -INFINITY;  // -inf entries can only be re-selected when fewer than K finite values exist
     }
     __syncthreads();
   }
@@ -136,12 +136,45 @@ __global__ void head_decode_kernel(DecL L, float* __restrict__ y, int B) {
 }
 
 // preds y (B, C, A) fp32 with `nc` score rows first: reg (B,K,C-nc), scores (B,K), labels (B,K) int64
+// hi-res maps, stage 1: block (seg, b) scores the anchors of its segment (max over classes) in LDS and keeps their K best
+__global__ __launch_bounds__(256) void postprocess_seg_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first, int seglen,
+                                                              float* __restrict__ scratch) {
+  extern __shared__ float sm[];
+  float* vals = sm;            // [seglen]
+  float* sv = sm + seglen;     // [256]
+  int* si = (int*)(sv + 256);  // [256]
+  int* top = si + 256;         // [K]
+  float* tv = (float*)(top + K);  // [K]
+  const int seg = blockIdx.x, nseg = gridDim.x, b = blockIdx.y;
+  const float* yb = y + (long)b * C * A;
+  const int s0 = boxes_first ? C - nc : 0;
+  const int a0 = seg * seglen;
+  const int n = min(seglen, A - a0);
+  for (int a = threadIdx.x; a < n; a += 256) {
+    float m = yb[(long)s0 * A + a0 + a];
+    for (int c = 1; c < nc; ++c) m = fmaxf(m, yb[(long)(s0 + c) * A + a0 + a]);
+    vals[a] = m;
+  }
+  __syncthreads();
+  const int kk = min(K, n);
+  block_topk(vals, n, kk, top, tv, sv, si);
+  float* cv = scratch + ((long)b * nseg + seg) * K;
+  int* ci = (int*)(scratch + (long)gridDim.y * nseg * K) + ((long)b * nseg + seg) * K;
+  for (int i = threadIdx.x; i < K; i += 256) {
+    cv[i] = i < kk ? tv[i] : -INFINITY;
+    ci[i] = i < kk ? a0 + top[i] : 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first,
                                                           float* __restrict__ reg, float* __restrict__ scores, long* __restrict__ labels,
-                                                          float* __restrict__ scratch) {
+                                                          float* __restrict__ scratch, int nseg) {
   extern __shared__ float sm[];
-  float* vals = scratch ? scratch + (long)blockIdx.x * A : sm;  // [A]: LDS when it fits, else the caller's HBM scratch (hi-res maps)
-  float* sv = scratch ? sm : sm + A;  // [256]
+  // scratch == nullptr: the A per-anchor scores live in LDS.  Otherwise (hi-res maps) postprocess_seg_kernel has already picked the
+  // K best anchors of each of `nseg` anchor segments: scratch holds their values [B][nseg*K] and anchor indices [B][nseg*K]
+  const int ncand = scratch ? nseg * K : A;
+  float* vals = sm;           // [ncand]
+  float* sv = sm + ncand;     // [256]
   int* si = (int*)(sv + 256);   // [256]
   int* top = si + 256;          // [K]
   float* sc2 = (float*)(top + K);  // [K*nc]
@@ -152,13 +185,23 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
   const int s0 = boxes_first ? C - nc : 0;   // first score row
   const int r0 = boxes_first ? 0 : nc;       // first regression row
   const int nr = C - nc;
-  for (int a = threadIdx.x; a < A; a += 256) {
-    float m = yb[(long)s0 * A + a];
-    for (int c = 1; c < nc; ++c) m = fmaxf(m, yb[(long)(s0 + c) * A + a]);
-    vals[a] = m;
+  if (scratch) {
+    const float* cv = scratch + (long)b * ncand;
+    for (int a = threadIdx.x; a < ncand; a += 256) vals[a] = cv[a];
+  } else {
+    for (int a = threadIdx.x; a < A; a += 256) {
+      float m = yb[(long)s0 * A + a];
+      for (int c = 1; c < nc; ++c) m = fmaxf(m, yb[(long)(s0 + c) * A + a]);
+      vals[a] = m;
+    }
   }
   __syncthreads();
-  block_topk(vals, A, K, top, nullptr, sv, si);
+  block_topk(vals, ncand, K, top, nullptr, sv, si);
+  if (scratch) {  // candidate position -> anchor index (positions are ordered by segment, then by rank: ties keep the lowest anchor first)
+    const int* ci = (const int*)(scratch + (long)gridDim.x * ncand) + (long)b * ncand;
+    for (int i = threadIdx.x; i < K; i += 256) top[i] = ci[top[i]];
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < K * nc; i += 256) sc2[i] = yb[(long)(s0 + i % nc) * A + top[i / nc]];
   __syncthreads();
   block_topk(sc2, K * nc, K, top2, val2, sv, si);
@@ -311,10 +354,22 @@ int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det
   const bool fits = y3d_v10_postprocess_scratch_floats(B, A, nc, max_det) == 0;
   Y3D_CHECK(fits || scratch, "v10_postprocess: %d anchors do not fit LDS and no scratch was given (y3d_v10_postprocess_scratch_floats)", A);
   if (fits) scratch = nullptr;
-  size_t sm = (size_t)((fits ? A : 0) + 512 + max_det * (nc + 3)) * 4;
+  // hi-res: segments of anchors whose K best are merged by the second stage; candidates (values + indices) must fit the B*A scratch
+  int nseg = 0, seglen = 0;
+  if (!fits) {
+    nseg = 16;
+    while (nseg > 1 && (long)nseg * max_det * 2 > A) nseg >>= 1;
+    seglen = cdiv(A, nseg);
+    Y3D_CHECK((long)nseg * max_det * 2 <= A && (size_t)(seglen + 512 + 2 * max_det) * 4 <= 160 * 1024, "v10_postprocess: %d anchors with max_det %d", A, max_det);
+    size_t sm1 = (size_t)(seglen + 512 + 2 * max_det) * 4;
+    (void)hipFuncSetAttribute((const void*)postprocess_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(postprocess_seg_kernel, dim3(nseg, B), dim3(256), sm1, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, seglen, scratch);
+  }
+  size_t sm = (size_t)((fits ? A : nseg * max_det) + 512 + max_det * (nc + 3)) * 4;
   Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: max_det * nc = %d does not fit LDS", max_det * nc);
   (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch);
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch,
+                     nseg);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }
