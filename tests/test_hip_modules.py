@@ -643,7 +643,8 @@ def test_attention_mfma_vs_valu(shape):
     check(res[1], ref, 2e-2, "attention MFMA vs fp32 math")
 
 
-@pytest.mark.parametrize("shape", [(2, 20, 20, 2), (1, 7, 11, 1), (1, 40, 40, 4), (3, 20, 20, 2)])
+# N = 1600 and N = 621: the LDS images of the MFMA backward hold 1024 keys / 512 queries, longer sequences walk them in passes
+@pytest.mark.parametrize("shape", [(2, 20, 20, 2), (1, 7, 11, 1), (1, 40, 40, 4), (3, 20, 20, 2), (1, 23, 27, 2)])
 def test_attention_backward_mfma_vs_valu_and_autograd(shape):
     """bf16 PSA attention backward: the MFMA kernels (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS) vs the fp32-VALU kernels and vs
     torch autograd on plain fp32 math; the second output (v, consumed by the positional-encoding branch) feeds dv_extra"""

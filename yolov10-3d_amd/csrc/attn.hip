@@ -86,6 +86,7 @@ struct AttnBP {
   float* delta;                  // [B][nh][N]
   int B, N, nh, kd, hd;
   float scale;
+  int chunk;                     // MFMA kernels: rows of the LDS image per pass (multiple of 32); N > chunk walks the image in passes
 };
 
 // dq_i = scale * sum_j ds_ij k_j,   ds_ij = p_ij (do_i . v_j - delta_i)
@@ -346,12 +347,6 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
   const int hoff = h * (2 * KD + HD);
   const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
   const int n32 = (p.N + 31) & ~31;
-  for (int id = tid; id < n32 * 4; id += 256) {  // K image: 4 chunks of 16 B per key
-    const int P = id >> 2, s4 = id & 3;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (P < p.N) v = *(const uint4*)(base + (long)P * p.qsw + KD + s4 * 8);
-    *(uint4*)(sK + P * 128 + ((s4 ^ (((P >> 1) & 3) << 1)) << 4)) = v;
-  }
   const bool qv = q0 + li < p.N;
   const bf16x8_t fq = qv ? ld8(base + (long)(q0 + li) * p.qsw + 8 * grp) : zero8();
   bf16x8_t fdo[2];
@@ -375,13 +370,22 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
       if (grp == 0) p.delta[((long)b * p.nh + h) * p.N + q0 + li] = delta;
     }
   }
-  __syncthreads();
   f32x4_t dq[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-  for (int ks = 0; ks < n32 / 32; ++ks) {
+  for (int cb = 0; cb < n32; cb += p.chunk) {  // the K image holds p.chunk keys: long sequences (hi-res maps) walk it in passes
+  const int cn = min(p.chunk, n32 - cb);
+  if (cb) __syncthreads();  // the previous pass's readers are done with the image
+  for (int id = tid; id < cn * 4; id += 256) {  // K image: 4 chunks of 16 B per key
+    const int Pl = id >> 2, s4 = id & 3, P = cb + Pl;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (P < p.N) v = *(const uint4*)(base + (long)P * p.qsw + KD + s4 * 8);
+    *(uint4*)(sK + Pl * 128 + ((s4 ^ (((Pl >> 1) & 3) << 1)) << 4)) = v;
+  }
+  __syncthreads();
+  for (int ks = 0; ks < cn / 32; ++ks) {
     float dsv[8];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
-      const int key = 32 * ks + 16 * hi + li;  // this lane's row of the A operands
+      const int key = cb + 32 * ks + 16 * hi + li;  // this lane's row of the A operands
       const bool kv = key < p.N;
       const T* kp = base + (long)key * p.qsw;
       const bf16x8_t fk = kv ? ld8(kp + KD + 8 * grp) : zero8();
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = qv && 32 * ks + 16 * hi + 4 * grp + r < p.N;
+        const bool ok = qv && cb + 32 * ks + 16 * hi + 4 * grp + r < p.N;
         dsv[hi * 4 + r] = ok ? __expf(s[r] * p.scale - lse) * (dpt[r] - delta) : 0.f;
       }
     }
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
     for (int j = 0; j < 8; ++j) fds[j] = (__bf16)dsv[j];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<128>(sK, ks, dt * 16, grp, qq, pp4), fds, dq[dt], 0, 0, 0);
+  }
   }
   if (qv) {
     T* dst = (T*)p.dqkv + ((long)b * p.N + q0 + li) * p.gsw + hoff;
@@ -428,12 +433,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
   const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
   const T* dob = (const T*)p.dout + (long)b * p.N * p.dsw + h * HD;
   const int n32 = (p.N + 31) & ~31;
-  for (int id = tid; id < n32 * 12; id += 256) {  // 12 chunks per query: 8 of dO, 4 of Q
-    const int P = id / 12, c = id - P * 12;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (P < p.N) v = c < 8 ? *(const uint4*)(dob + (long)P * p.dsw + c * 8) : *(const uint4*)(base + (long)P * p.qsw + (c - 8) * 8);
-    *(uint4*)(sI + P * 256 + ((c ^ ((P & 7) << 1)) << 4)) = v;
-  }
   const bool kv = k0 + li < p.N;
   const T* kp = base + (long)(k0 + li) * p.qsw;
   const bf16x8_t fk = kv ? ld8(kp + KD + 8 * grp) : zero8();  // B operands: this lane's key
@@ -442,16 +441,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
   for (int k2 = 0; k2 < 2; ++k2) fv[k2] = kv ? ld8(kp + 2 * KD + 32 * k2 + 8 * grp) : zero8();
   const float* lsep = p.lse + ((long)b * p.nh + h) * p.N;
   const float* delp = p.delta + ((long)b * p.nh + h) * p.N;
-  __syncthreads();
   f32x4_t dv[4], dk[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   dk[0] = dk[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int ks = 0; ks < n32 / 32; ++ks) {
+  for (int cb = 0; cb < n32; cb += p.chunk) {  // the dO | Q image holds p.chunk queries per pass
+  const int cn = min(p.chunk, n32 - cb);
+  if (cb) __syncthreads();
+  for (int id = tid; id < cn * 12; id += 256) {  // 12 chunks per query: 8 of dO, 4 of Q
+    const int Pl = id / 12, c = id - Pl * 12, P = cb + Pl;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (P < p.N) v = c < 8 ? *(const uint4*)(dob + (long)P * p.dsw + c * 8) : *(const uint4*)(base + (long)P * p.qsw + (c - 8) * 8);
+    *(uint4*)(sI + Pl * 256 + ((c ^ ((Pl & 7) << 1)) << 4)) = v;
+  }
+  __syncthreads();
+  for (int ks = 0; ks < cn / 32; ++ks) {
     float pv[8], dsv[8];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
-      const int qi = 32 * ks + 16 * hi + li;  // this lane's row of the A operands
+      const int qi = cb + 32 * ks + 16 * hi + li;  // this lane's row of the A operands
       const bool qv = qi < p.N;
       const bf16x8_t fq = qv ? ld8(base + (long)qi * p.qsw + 8 * grp) : zero8();
       f32x4_t s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fk, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qr = 32 * ks + 16 * hi + 4 * grp + r;  // the query of register r
+        const int qr = cb + 32 * ks + 16 * hi + 4 * grp + r;  // the query of register r
         const bool ok = kv && qr < p.N;
         const float pe = ok ? __expf(s[r] * p.scale - lsep[qr]) : 0.f;
         pv[hi * 4 + r] = pe;
@@ -477,6 +485,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
     for (int ct = 0; ct < 4; ++ct) dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<256>(sI, ks, ct * 16, grp, qq, pp4), fp, dv[ct], 0, 0, 0);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<256>(sI, ks, 64 + dt * 16, grp, qq, pp4), fds, dk[dt], 0, 0, 0);
+  }
   }
   if (kv) {
     T* dst = (T*)p.dqkv + ((long)b * p.N + k0 + li) * p.gsw + hoff;
@@ -540,20 +549,23 @@ int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64
                  int kd, int hd, float scale, void* stream) {
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "attn_bwd: bad dtype");
   Y3D_CHECK((kd == 32 && hd == 64) || (kd == 36 && hd == 72), "attn_bwd: unsupported head dims kd=%d hd=%d", kd, hd);
-  AttnBP p{qkv, (long)qsw, out, (long)osw, dout, (long)dsw, dv_extra, (long)esw, dqkv, (long)gsw, lse, delta, B, N, nh, kd, hd, scale};
+  AttnBP p{qkv, (long)qsw, out, (long)osw, dout, (long)dsw, dv_extra, (long)esw, dqkv, (long)gsw, lse, delta, B, N, nh, kd, hd, scale, 0};
   dim3 grid(cdiv(N, 128), B * nh), block(128);
   hipStream_t st = (hipStream_t)stream;
   const int n32 = (N + 31) & ~31;
   if (dtype == Y3D_BF16 && kd == 32 && y3d_get_tile_kernels() && qsw % 8 == 0 && osw % 8 == 0 && dsw % 8 == 0 && gsw % 4 == 0 &&
-      (dv_extra == nullptr || esw % 1 == 0) && (size_t)n32 * 256 <= 160 * 1024) {
+      (dv_extra == nullptr || esw % 1 == 0)) {
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)n32 * 128, st, p);
-    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)n32 * 256, st, p);
+    // LDS images of at most 128 KB: 1024 keys (128-byte rows) / 512 queries (256-byte rows) per pass; N = 400 is one pass
+    p.chunk = n32 < 1024 ? n32 : 1024;
+    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)p.chunk * 128, st, p);
+    p.chunk = n32 < 512 ? n32 : 512;
+    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)p.chunk * 256, st, p);
     Y3D_LAUNCH_CHECK();
     return Y3D_OK;
   }
