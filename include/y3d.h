@@ -150,6 +150,9 @@ int y3d_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int B, int C,
 /* stem (nn/tasks.py yaml row 0: Conv(3, c, 3, 2)): NCHW fp32 image -> [B][Ho][Wo][32], column (r*3+q)*3+ci of the 3x3 stride-2 pad-1
  * window, columns 27..31 zero; the stem conv is then y3d_conv2d_fwd / _bwd_weight with a 1x1 kernel over 32 channels */
 int y3d_stem_im2col(int dtype, const float* x_nchw, void* out, int B, int H, int W, int Ho, int Wo, void* stream);
+/* the same from the dataset's uint8 image (NCHW: hwc = 0, NHWC as decoded: hwc = 1) with the /255 of data/datasets/kitti.py:204-205
+ * (models/yolo/detect/train.py:59 for the 2D trainer) done on the device: 1 byte per sample crosses PCIe / HBM instead of 4 */
+int y3d_stem_im2col_u8(int dtype, const uint8_t* x, int hwc, void* out, int B, int H, int W, int Ho, int Wo, void* stream);
 int y3d_nhwc_to_nchw(int dtype, const void* x_nhwc, int64_t xsw, float* y_nchw, int B, int C, int H, int W, void* stream);
 /* head final nn.Conv2d(c, out, 1) with bias, out <= 24 — head.py:637 (3D branches: nc,2,2,2,3,24,1,1) */
 int y3d_proj_fwd(int dtype, const void* x, int64_t xsw, const float* w, const float* bias, void* y, int64_t ysw, int64_t P,

@@ -817,6 +817,31 @@ def test_eval_after_more_training_sees_new_weights():
         y3d.set_compute_dtype(torch.bfloat16)
 
 
+def test_uint8_images_match_host_normalised_images():
+    """the stem takes the dataset's uint8 image (NCHW, or NHWC as decoded) and divides by 255 on the device: bit-identical to feeding the
+    float image the reference's dataset builds on the host (data/datasets/kitti.py:204-205)"""
+    from bench import synth_batch
+    for dtype in (torch.float32, torch.bfloat16):
+        y3d.set_compute_dtype(dtype)
+        torch.manual_seed(0)
+        model = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml").to(DEV).train()
+        batch = synth_batch(2, 256, 256, 1, DEV)
+        img8 = torch.randint(0, 256, (2, 3, 256, 256), dtype=torch.uint8, device=DEV)
+        outs = []
+        import numpy as np
+        host = torch.from_numpy(img8.cpu().numpy().astype(np.float32) / np.float32(255.0)).to(DEV)  # IEEE division, as numpy on the host
+        for img in (host, img8, img8.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)):
+            b = dict(batch)
+            b["img"] = img
+            model.zero_grad(set_to_none=True)
+            loss, items = model(b)
+            loss.backward()
+            outs.append((items.clone(), model.model[0].conv.weight.grad.clone()))
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    y3d.set_compute_dtype(torch.bfloat16)
+
+
 def test_fused_adamw_matches_torch():
     """clip_grad_norm_(10) + AdamW(betas=(0.9, 0.999), per-group decay) vs torch.optim.AdamW, 4 steps (tolerance: torch's lerp /
     addcdiv kernels may contract to FMAs, ours are compiled with -ffp-contract=off)"""

@@ -361,6 +361,36 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ 
   }
 }
 
+// The same from the dataset's uint8 image, NCHW (hwc = 0) or NHWC as decoded (hwc = 1): v = u8 / 255 in fp32 -- the reference divides
+// on the host (data/datasets/kitti.py:204-205: astype(float32) / 255) and ships 4 bytes per sample; bit-identical to that float image.
+template <typename T>
+__global__ void stem_im2col_u8_kernel(const unsigned char* __restrict__ x, int hwc, T* __restrict__ out, int B, int H, int W, int Ho, int Wo) {
+  constexpr int CE = TT<T>::CE;
+  constexpr int CPP = 32 / CE;
+  long total = (long)B * Ho * Wo * CPP;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % CPP);
+    long pidx = i / CPP;
+    const int ow = (int)(pidx % Wo);
+    pidx /= Wo;
+    const int oh = (int)(pidx % Ho);
+    const int b = (int)(pidx / Ho);
+    float v[CE];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) {
+      const int k = ch * CE + j;
+      const int tap = k / 3, ci = k - tap * 3;
+      const int r = tap / 3, q = tap - r * 3;
+      const int ih = 2 * oh - 1 + r, iw = 2 * ow - 1 + q;
+      float u = 0.f;
+      if (k < 27 && ih >= 0 && ih < H && iw >= 0 && iw < W)
+        u = (float)(hwc ? x[(((long)b * H + ih) * W + iw) * 3 + ci] : x[(((long)b * 3 + ci) * H + ih) * W + iw]) / 255.f;
+      v[j] = u;
+    }
+    *(uint4*)(out + i * CE) = Chunk<T>::pack(v);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, KERNEL, grid, block, sm, st, ...)                                   \
@@ -455,6 +485,16 @@ int y3d_stem_im2col(int dtype, const float* x_nchw, void* out, int B, int H, int
   long total = (long)B * Ho * Wo * (dtype == Y3D_BF16 ? 4 : 8);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, H, W, Ho, Wo);
   else hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, (float*)out, B, H, W, Ho, Wo);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_stem_im2col_u8(int dtype, const uint8_t* x, int hwc, void* out, int B, int H, int W, int Ho, int Wo, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "stem_im2col_u8: bad dtype");
+  Y3D_CHECK(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "stem_im2col_u8: output size of a 3x3 stride-2 pad-1 conv expected");
+  long total = (long)B * Ho * Wo * (dtype == Y3D_BF16 ? 4 : 8);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(stem_im2col_u8_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, hwc, (bf16_t*)out, B, H, W, Ho, Wo);
+  else hipLaunchKernelGGL(stem_im2col_u8_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, hwc, (float*)out, B, H, W, Ho, Wo);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

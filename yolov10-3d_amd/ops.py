@@ -250,7 +250,12 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         # the stem: im2col the image once (27 window values + 5 zeros per output pixel) and run a dense 1x1 conv with K = 32;
         # as a 9-tap conv over an 8-channel-padded image the MFMA tiles were 86 % padding.  dW is mapped back in _cba_backward.
         xcol = nhwc_empty(B, 32, Ho, Wo, dtype, dev)
-        L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
+        if x.dtype == torch.uint8:  # the dataset's bytes: /255 happens in the kernel (NCHW, or NHWC when the tensor is channels-last)
+            hwc = int(not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous())
+            xs = x if (hwc or x.is_contiguous()) else x.contiguous()
+            L.stem_im2col_u8(dt, xs.data_ptr(), hwc, xcol.data_ptr(), B, H, W, Ho, Wo, st)
+        else:
+            L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
         wcol = torch.zeros(Cout, 32, dtype=torch.float32, device=dev)
         wcol[:, :27] = w32.detach().permute(0, 2, 3, 1).reshape(Cout, 27)  # column (r*3+q)*3+ci
         z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache,
