@@ -367,25 +367,48 @@ class v10Detect3d(nn.Module):
         return ys, embs
 
     def _stacks(self, i):
-        """StackedConvs of level i over [o2o branches 0..7, o2m branches 0..7] for layer 1 and (uniform widths only) layer 2"""
+        """StackedConvs of level i over [o2o branches 0..7, o2m branches 0..7] for layer 1 and layer 2.
+        -> (branches, mids, s1, s2, parts).  Uniform widths: s2 is ONE grouped stack, parts is None, the stack order is the branch
+        order.  cls wider than the seven regression branches (M-3D: 128 vs 64): `branches` / `mids` are in STACK order
+        [o2o cls, o2o regs, o2m regs, o2m cls] (the one-to-one half stays first: its input is detached), s2 is None and parts lists the
+        second layer as (lo, hi, stack, groups) over z1's channels: cls | 14 regression branches as one grouped conv | cls;
+        `pos[c]` maps the canonical branch index c (o2o 0..7, o2m 8..15) to its stack position."""
         key = (i, id(self.o2o_heads), id(self.o2m_heads))
         cache = self.__dict__.setdefault("_stack_cache", {})
         if key not in cache:
-            branches = [h[i] for h in self.o2o_heads] + [h[i] for h in self.o2m_heads]
-            mids = [b[0].conv.out_channels for b in branches]
-            s1 = ops.StackedConvs([b[0] for b in branches])
-            s2 = ops.StackedConvs([b[1] for b in branches], groups=len(branches)) if len(set(mids)) == 1 else None
-            cache[key] = (branches, mids, s1, s2)
+            canon = [h[i] for h in self.o2o_heads] + [h[i] for h in self.o2m_heads]
+            cm = [b[0].conv.out_channels for b in canon]
+            k2 = [b[1].conv.kernel_size for b in canon]
+            if len(set(cm)) == 1:
+                s1 = ops.StackedConvs([b[0] for b in canon])
+                s2 = ops.StackedConvs([b[1] for b in canon], groups=len(canon))
+                cache[key] = (canon, cm, s1, s2, None, list(range(16)))
+            elif len(set(cm[1:8] + cm[9:16])) == 1 and cm[0] == cm[8] and len(set(k2)) == 1 and cm[1] % 8 == 0 and cm[0] % 8 == 0:
+                order = list(range(0, 8)) + list(range(9, 16)) + [8]
+                branches = [canon[c] for c in order]
+                mids = [cm[c] for c in order]
+                pos = [order.index(c) for c in range(16)]
+                s1 = ops.StackedConvs([b[0] for b in branches])
+                c, m = mids[0], mids[1]
+                parts = [(0, c, ops.StackedConvs([branches[0][1]]), 1),
+                         (c, c + 14 * m, ops.StackedConvs([b[1] for b in branches[1:15]], groups=14), 14),
+                         (c + 14 * m, 2 * c + 14 * m, ops.StackedConvs([branches[15][1]]), 1)]
+                cache[key] = (branches, mids, s1, None, parts, pos)
+            else:
+                s1 = ops.StackedConvs([b[0] for b in canon])
+                cache[key] = (canon, cm, s1, None, None, list(range(16)))
         return cache[key]
 
     def restack(self):
         """(re)establish the stacked parameter storage of the fused training forward now (e.g. before wrapping the model in
         DistributedDataParallel, after .to(device) / load_state_dict(assign=True) / deepcopy)"""
         for i in range(self.nl):
-            _, _, s1, s2 = self._stacks(i)
+            _, _, s1, s2, parts, _ = self._stacks(i)
             s1.tensors()
             if s2 is not None:
                 s2.tensors()
+            for part in parts or ():
+                part[2].tensors()
 
     def forward_train_fused(self, x):
         """Both head sets of one level as: ONE 3x3 conv Cin -> sum(mid) (the one-to-one half contributes no input gradient:
@@ -393,7 +416,7 @@ class v10Detect3d(nn.Module):
         (B, 2*no, H, W) map.  Numerically identical to the per-branch form (BatchNorm is per channel)."""
         o2o, o2m, e_o2o, e_o2m = [], [], [], []
         for i in range(self.nl):
-            branches, mids, s1, s2 = self._stacks(i)
+            branches, mids, s1, s2, parts, pos = self._stacks(i)
             half = sum(mids[:8])
             z1 = ops.FusedConvBNActFn.apply(x[i], s1, 1, (half, sum(mids)), *s1.params())
             offs = [sum(mids[:j]) for j in range(16)]
@@ -404,13 +427,26 @@ class v10Detect3d(nn.Module):
             elif s2 is not None:
                 z2 = ops.FusedConvBNActFn.apply(z1, s2, len(branches), None, *s2.params())
                 out = ops.HeadProjSlicesFn.apply(z2, offs, mids, 16, *[b[2].weight for b in branches], *[b[2].bias for b in branches])
+            elif parts is not None:
+                # cls | 14 regression branches (one grouped conv) | cls over channel views of z1; every split hands ONE gradient back
+                views = ops.SplitChannelsFn.apply(z1, [lo for lo, _, _, _ in parts], [hi - lo for lo, hi, _, _ in parts])
+                feats_s = []
+                for v, (lo, hi, st2, g) in zip(views, parts):
+                    z2 = ops.FusedConvBNActFn.apply(v, st2, g, None, *st2.params())
+                    if g == 1:
+                        feats_s.append(z2)
+                    else:
+                        w = (hi - lo) // g
+                        feats_s.extend(ops.SplitChannelsFn.apply(z2, [j * w for j in range(g)], [w] * g))
+                canon = [branches[pos[c]] for c in range(16)]
+                out = _proj([b[2] for b in canon], [feats_s[pos[c]] for c in range(16)])
             else:
                 feats = [b[1](zj) for b, zj in zip(branches, ops.SplitChannelsFn.apply(z1, offs, mids))]
                 out = _proj([b[2] for b in branches], feats)
             o2o.append(out[:, : self.no])
             o2m.append(out[:, self.no:])
-            e_o2o.append(z1[:, offs[6]:offs[6] + mids[6]])
-            e_o2m.append(z1[:, offs[14]:offs[14] + mids[14]])
+            e_o2o.append(z1[:, offs[pos[6]]:offs[pos[6]] + mids[pos[6]]])
+            e_o2m.append(z1[:, offs[pos[14]]:offs[pos[14]] + mids[pos[14]]])
         return o2o, o2m, e_o2o, e_o2m
 
     # ---- sparse (eval) path: head.py:656-716 -----------------------------------------------------------------
@@ -439,7 +475,7 @@ class v10Detect3d(nn.Module):
             patches = ops.nhwc_empty(B * K, C, ps, ps, xi.dtype, xi.device)
             sb, sh, sw = ops.s3(xi)
             L.patch_gather(dt, xi.data_ptr(), sb, sh, sw, idx.data_ptr(), patches.data_ptr(), B, H, W, C, K, ps, st)
-            _, mids, s1, s2 = self._stacks(i)
+            _, mids, s1, s2, _, _ = self._stacks(i)
             if heads is self.o2o_heads and s2 is not None:
                 # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
                 # (channel rows mid..8*mid of the training-time stacks), both unpadded: patch semantics of head.py:706-708
