@@ -174,6 +174,12 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     const int bb = c.b0 + img, yy = c.y0 + hy - 1, xx = c.x0 + hx - 1;
     const bool inb = (c.live != 0) & (bb < p.B) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
     const unsigned off = (unsigned)(bb * (int)p.xsb + yy * (int)p.xsh + xx * (int)p.xsw + c.g * p.Cg + slab * 32 + ((s ^ (((hx >> 2) & 1) << 1)) << 3)) * 2u;
+#ifdef Y3D_PROBE_CHEAPADDR  // upper bound of what cheaper halo address arithmetic could give (wrong data)
+    if (rd < HFULL || chunk < HCH)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
+                                               (unsigned)(l * 16 + rd * 4096 + slab * 64), 0, 0, 0);
+    return;
+#endif
     if (rd < HFULL || chunk < HCH)  // lanes past the end of the last (partial) round must not write LDS
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
                                                inb ? off : OOB, 0, 0, 0);
