@@ -168,12 +168,17 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     const int P = chunk >> 2, s = chunk & 3;
     int img = P >= NPIX;
     if (NB > 2) img += (P >= 2 * NPIX) + (P >= 3 * NPIX);
-    const int pp = P - img * NPIX;
-    const int hy = (pp * 3641) >> 16;  // pp / 18, exact for pp < 8192
-    const int hx = pp - hy * HWD;
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate and this runs ~20 times per slab between the MFMAs): every factor is
+    // far below 2^23 (pixel strides: the launcher checks), the image term needs no multiply at all
+    const int pp = P - __mul24(img, NPIX);
+    const int hy = __mul24(pp, 3641) >> 16;  // pp / 18, exact for pp < 8192
+    const int hx = pp - __mul24(hy, HWD);
     const int bb = c.b0 + img, yy = c.y0 + hy - 1, xx = c.x0 + hx - 1;
     const bool inb = (c.live != 0) & (bb < p.B) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
-    const unsigned off = (unsigned)(bb * (int)p.xsb + yy * (int)p.xsh + xx * (int)p.xsw + c.g * p.Cg + slab * 32 + ((s ^ (((hx >> 2) & 1) << 1)) << 3)) * 2u;
+    const int xsb = (int)p.xsb;
+    const int imgoff = NB > 2 ? ((img & 1) ? xsb : 0) + ((img & 2) ? 2 * xsb : 0) : (img ? xsb : 0);
+    const unsigned off = (unsigned)(c.b0 * xsb + imgoff + __mul24(yy, (int)p.xsh) + __mul24(xx, (int)p.xsw) + c.g * p.Cg + slab * 32 +
+                                    ((s ^ (((hx >> 2) & 1) << 1)) << 3)) * 2u;
 #ifdef Y3D_PROBE_CHEAPADDR  // upper bound of what cheaper halo address arithmetic could give (wrong data)
     if (rd < HFULL || chunk < HCH)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
@@ -194,7 +199,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
       const int chunk = rd * LH + l, n = chunk >> 2, s = chunk & 3;
-      const unsigned wrel = (unsigned)(n * p.Ktot + ((s ^ (((n >> 4) & 1) << 1)) << 3)) * 2u;  // recomputed: no resident registers
+      const unsigned wrel = (unsigned)(__mul24(n, p.Ktot) + ((s ^ (((n >> 4) & 1) << 1)) << 3)) * 2u;  // recomputed: no resident registers
       const bool ok = (c.live != 0) & (c.c0 + n < p.Cn);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sW + slot * WB + (rd * LH + (wave - 4) * 64) * 16), 16,
                                                ok ? base + wrel : OOB, 0, 0, 0);
@@ -496,6 +501,7 @@ int y3d_conv3x3_wide_launch(int th, const void* x, long xsb, long xsh, long xsw,
   const unsigned long xb = ((unsigned long)(B - 1) * xsb + (unsigned long)(H - 1) * xsh + (unsigned long)(W - 1) * xsw + (unsigned long)G * Cg) * 2;
   const unsigned long wb = (unsigned long)G * Cn * Ktot * 2;
   Y3D_CHECK(xb < 0xfffffff0ul && wb < 0xfffffff0ul, "conv3x3_wide: operand larger than 4 GB");
+  Y3D_CHECK(xsh < (1L << 23) && xsw < (1L << 23) && Ktot < (1 << 23), "conv3x3_wide: pixel strides beyond the 24-bit address multiplies");
   p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   if (th == 16) return scale ? launch_wide<16, 1>(p, st) : launch_wide<16, 0>(p, st);
