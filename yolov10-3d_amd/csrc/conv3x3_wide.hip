@@ -185,6 +185,16 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
                                                (unsigned)(l * 16 + rd * 4096 + slab * 64), 0, 0, 0);
     return;
 #endif
+#ifdef Y3D_PROBE_CONTIG  // the full address arithmetic, kept live, but a contiguous (wrong) address in the load: isolates memory locality
+    {
+      unsigned keep = inb ? off : OOB;
+      asm volatile("" ::"v"(keep));
+      if (rd < HFULL || chunk < HCH)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
+                                                 (unsigned)(l * 16 + rd * 4096 + slab * 64), 0, 0, 0);
+      return;
+    }
+#endif
     if (rd < HFULL || chunk < HCH)  // lanes past the end of the last (partial) round must not write LDS
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
                                                inb ? off : OOB, 0, 0, 0);
