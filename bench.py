@@ -1,6 +1,8 @@
 """bench.py — images/sec of the YOLOv10-S-3D 640x640 hot path on N MI355X (one process per GPU, RCCL over xGMI).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8            # no launcher: spawns its 8 ranks itself (child `python -m torch.distributed.run ...`, the
+                                        # reference's own scheme, utils/dist.py:55-65) before touching the GPU, relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one training pass of the hot path over one synthetic batch that is already resident in HBM:
@@ -13,7 +15,10 @@ Extra objects on that line:
                  timed live with HIP events on the launch stream during the timed region; algorithmic FLOPs
                  2*B*Ho*Wo*Cout*Cin*9 per launch against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline — the CPU oracle restatement (oracle/restate.py, fp32, all host cores) on a bounded sample of the same
-                 workload (B=2 steps), kind "port".  A reported baseline, never the product path.
+                 workload (B=2 steps, 2 warm-ups + median of 5), kind "port".  A reported baseline, never the product path.
+
+The timed loop rotates over NBATCH pre-staged batch dicts (different seeds, all resident in HBM), so every step sees a batch it
+has not just processed and per-batch work (target padding, its kernels) is inside the timed region, as in the reference's loop.
 """
 from __future__ import annotations
 
@@ -57,7 +62,27 @@ def synth_batch(B, H, W, seed, device, nc=3):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def cpu_baseline(model_name, imgsz, seed, steps=2, B=2):
+NBATCH = 4
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (torch.distributed.run), before this
+    process has made any HIP call, hand through stdout / stderr (rank 0 prints the JSON line) and return the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's buffer exchange needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(model_name, imgsz, seed, steps=5, B=2, warm=2):
     """oracle restatement (fp32) timed on the host cores: fwd + loss + bwd on a bounded sample (B=2 per step)."""
     import yaml
 
@@ -78,18 +103,18 @@ def cpu_baseline(model_name, imgsz, seed, steps=2, B=2):
     batch = synth_batch(B, imgsz, imgsz, seed, "cpu")
     strides = RS.model_strides(spec)
     times = []
-    for i in range(steps + 1):
+    for i in range(steps + warm):
         t0 = time.perf_counter()
         preds = RS.forward(spec, st, batch["img"], True)
         loss, items, _ = RS.loss3d(preds, batch, strides, 3)
         loss.backward()
         for p in params:
             p.grad = None
-        if i > 0:
+        if i >= warm:
             times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
     return {"value": B / t, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/restate.py fp32 train step (fwd+loss+bwd), {model_name} {imgsz}x{imgsz}, B={B}, median of {steps} steps after 1 warm-up"}
+            "sample": f"oracle/restate.py fp32 train step (fwd+loss+bwd), {model_name} {imgsz}x{imgsz}, B={B}, median of {steps} steps after {warm} warm-ups"}
 
 
 def log(msg):
@@ -110,7 +135,11 @@ def main():
     ap.add_argument("--infer-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--phases", action="store_true", help="N>1: per-phase device times (backward / all-reduce / optimizer) in the JSON line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # nothing in this process has touched the GPU yet
 
     import torch.distributed as dist
 
@@ -143,22 +172,42 @@ def main():
         if os.environ.get("Y3D_TORCH_DDP"):
             net = ddp.wrap(model, device_ids=[local])  # torch DistributedDataParallel (buckets as views)
         else:
-            reducer = ddp.FlatGradReducer(model.parameters())  # one gather launch + one RCCL all-reduce of the flat buffer per step
+            # head-first flat gradient buffer, bucketed RCCL all-reduce on a side stream behind the head backward
+            reducer = ddp.FlatGradReducer(model.parameters(), timing=args.phases)
             reducer.broadcast_parameters(model)
+            model.model[-1].restack()  # no-op check: the broadcast wrote in place, the stacked storage is still the parameters' storage
     B, S = args.batch, args.imgsz
-    batch = synth_batch(B, S, S, seed=1 + rank, device=dev)  # resident in HBM before the timed region
+    # NBATCH different batches resident in HBM before the timed region; the loop rotates over them
+    batches = [synth_batch(B, S, S, seed=1 + rank + 1000 * j, device=dev) for j in range(NBATCH)]
+    batch = batches[0]
+    counter = [0]
+    phase_ev = []
 
     def step():
-        loss, items = net(batch)
+        bt = batches[counter[0] % NBATCH]
+        counter[0] += 1
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if args.phases else None
+        if ev:
+            ev[0].record()
+        loss, items = net(bt)
         if reducer is not None:
             loss.backward()   # SUM all-reduce of the unscaled losses' gradients == reference's loss * world + averaged gradients
-            reducer.reduce()
+            if ev:
+                ev[1].record()
+            reducer.finish()  # compute stream waits for the bucket collectives that are still in flight
         else:
             ddp.scale_loss(loss, world).backward()  # reference trainer.py:401-402 (the all-reduce averages gradients)
+            if ev:
+                ev[1].record()
+        if ev:
+            ev[2].record()
         opt.step(max_norm=10.0)  # clip_grad_norm_(10) + SGD nesterov (trainer.py:570-571) in three multi-tensor launches
         opt.zero_grad(set_to_none=True)
         if ema is not None:
             ema.update(model)  # one multi-tensor launch over the whole state_dict
+        if ev:
+            ev[3].record()
+            phase_ev.append(ev)
         return items
 
     def sync():
@@ -180,6 +229,7 @@ def main():
     mid = model.model[-1].o2o_heads[0][0][1].conv.in_channels
     k1_key = ("conv_fwd", dt_code, B, P3, P3, 16 * mid, 16 * mid, 3, 1, 16)
     ops.TIMER = ops.KernelTimer(lambda key: key == k1_key)
+    phase_ev.clear()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -222,13 +272,17 @@ def main():
             flops = 2.0 * B * P3 * P3 * 16 * mid * mid * 9
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
-            traffic = None  # HBM bytes per launch of this kernel from the committed PMC passes (tools/pmc_summary.py); bench cannot run rocprof itself
-            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_headline.json")
+            # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the run, so this is the figure of the
+            # committed rocprofv3 passes over this same command (tools/pmc_summary.py), labelled with the commit they were taken at
+            traffic, traffic_src = None, None
+            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_headline.json")
             if os.path.exists(pj) and dtype == torch.bfloat16 and B == 32 and S == 640:
                 with open(pj) as f:
-                    traffic = json.load(f).get("traffic_bytes_per_launch")
+                    pm = json.load(f)
+                traffic = pm.get("traffic_bytes_per_launch")
+                traffic_src = "profiles/pmc_headline.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s)" % pm.get("commit", "?")
             roof = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<TH=16> %s (persistent resident-halo implicit GEMM) 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None
         if not args.no_cpu_baseline:
@@ -245,6 +299,14 @@ def main():
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if args.phases and phase_ev:
+            def med(i, j):
+                v = sorted(e[i].elapsed_time(e[j]) for e in phase_ev)
+                return round(v[len(v) // 2], 3)
+            out["phases_ms"] = {"fwd_loss_bwd": med(0, 1), "allreduce_exposed": med(1, 2), "clip_sgd_ema": med(2, 3)}
+            bt = reducer.times() if reducer is not None else None
+            if bt:
+                out["phases_ms"]["buckets"] = [{"MB": round(nb / 1e6, 1), "ready_to_done_ms": round(a, 3), "allreduce_ms": round(b, 3)} for nb, a, b in bt]
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

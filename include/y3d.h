@@ -202,12 +202,20 @@ int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64
  * (cls | box xyxy px | center_2d | size_2d | center_3d | size_3d | depth | heading_bin | heading_res).
  * ---------------------------------------------------------------------------------------------- */
 int y3d_tal3d_scratch_floats(int B, int n, int A, int topk);
+/* `preprocess` utils/loss.py:795-810 (3D: :848-856, 2D: :223-226): rows (nbox, 1+width) = [batch_idx | cls | box xywh in [0,1] | ...] ->
+ * out (B, cap, width) zero-padded per image in order of appearance, box scaled by (scale_x, scale_y) and converted to xyxy px.
+ * *n_used (device int) = largest per-image box count: the assigners take it as a DEVICE pointer, so — unlike the reference's
+ * host-side `counts.max()` — padding the targets needs no host synchronisation.  Boxes beyond `cap` per image are dropped. */
+int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, float scale_x, float scale_y, float* out, int* n_used,
+                    void* stream);
 /* outputs: fg_mask (B,A) uint8, target_gt_idx (B,A) int32, target_scores (B,A,nc) fp32 (normalised),
- * scal[0] = max(sum(target_scores), 1), scal[1] = number of foreground anchors */
+ * scal[0] = max(sum(target_scores), 1), scal[1] = number of foreground anchors.
+ * n = rows per image of gt (capacity, <= 64); n_used: device int from y3d_pad_targets (rows >= *n_used are padding in every
+ * image and are skipped), or NULL = all n rows are walked.  The results do not depend on n_used. */
 int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
                      int B, int nc, const float* gt, int n, const float* calib, const float* mean_sizes, int topk, float alpha,
                      float beta, float gamma, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
-                     void* stream);
+                     const int* n_used, void* stream);
 /* items[6] = (box2d, cls, depth, offset3d, size3d, heading) of loss.py:886-891; grads[l] (pixel stride gsw[l]) receives
  * grad_scale * d(sum(items))/d(map) for all nc+35 channels.  partials: 6 * ceil(B*A/256) floats */
 int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, void* const* grads, const int64_t* gsw, const int* H,
@@ -220,7 +228,7 @@ int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, v
  * scratch as y3d_tal3d_scratch_floats.  items[3] = (box, cls, dfl) incl. gains; partials: 3 * ceil(B*A/256) floats */
 int y3d_tal2d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
                      int B, int nc, const float* gt, int n, int topk, float alpha, float beta, float* scratch, uint8_t* fg_mask,
-                     int* target_gt_idx, float* target_scores, float* scal, void* stream);
+                     int* target_gt_idx, float* target_scores, float* scal, const int* n_used, void* stream);
 int y3d_loss2d(int dtype, int nl, const void* const* maps, const int64_t* psw, void* const* grads, const int64_t* gsw, const int* H,
                const int* W, const float* strides, int B, int nc, const float* gt, int n, const uint8_t* fg_mask,
                const int* target_gt_idx, const float* target_scores, const float* scal, float w_box, float w_cls, float w_dfl,

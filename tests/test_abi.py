@@ -46,3 +46,30 @@ def test_no_cpu_fallback():
     from yolov10_3d_amd import modules as M
     with pytest.raises(y3d.Y3DError):
         M.Conv(8, 8, 3)(torch.randn(1, 8, 4, 4))
+
+
+def test_no_kernel_needs_scratch():
+    """Every HIP kernel of the library compiles without scratch (register spills / run-time indexed private arrays).  In the LDS-DMA
+    pipelines (conv3x3_wide, conv3x3_wgrad_tile, conv3x3_tile) a scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the
+    prefetch of the next tile (conv3x3_wide.hip header).  The numbers are the compiler's own resource report
+    (`-Rpass-analysis=kernel-resource-usage`), recorded by csrc/build.py at every compile."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("y3d_build", os.path.join(ROOT, "yolov10-3d_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False)
+    usage = mod.resource_usage()
+    hip = [s for s in mod.sources() if s.endswith(".hip")]
+    assert set(hip) <= set(usage), f"no resource report for {set(hip) - set(usage)}"
+    n = 0
+    bad = []
+    for src, kernels in usage.items():
+        for name, u in kernels.items():
+            n += 1
+            if u.get("scratch", 0) != 0:
+                bad.append((src, name, u))
+    assert n >= 150, f"only {n} kernels reported"
+    assert not bad, f"kernels with scratch: {bad}"
+    # the headline kernel keeps its two-waves-per-SIMD register budget
+    wide = {k: v for k, v in usage["conv3x3_wide.hip"].items() if "conv3x3_wide_kernel" in k}
+    assert len(wide) == 4 and all(v["vgprs"] <= 256 for v in wide.values()), wide

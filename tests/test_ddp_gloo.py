@@ -66,10 +66,11 @@ def _worker(rank, world, port, ret):
 
 
 class _CpuReducer(ddp.FlatGradReducer):
-    """test-only: the gather launch (`y3d_mt_copy`, HIP) replaced by slot copies so that the collective logic runs over gloo on CPU"""
+    """test-only: the gather launch (`y3d_mt_copy`, HIP) replaced by slot copies so that the collective logic (bucket plan, hooks,
+    in-order launches, finish) runs over gloo on CPU"""
 
-    def _gather(self, active, grads):
-        for i, g in zip(active, grads):
+    def _gather(self, idx, grads):
+        for i, g in zip(idx, grads):
             self.views[i].copy_(g)
 
 
@@ -79,7 +80,8 @@ def _worker_flat(rank, world, port, ret):
     torch.manual_seed(rank)  # different initial weights per rank: broadcast_parameters must repair that
     net = TinyNet()
     net.c2.bias.requires_grad_(True)
-    red = _CpuReducer(net.parameters())
+    red = _CpuReducer(net.parameters(), bucket_mb=0.0005, overlap=True)  # tiny buckets: several collectives per step
+    assert len(red.buckets) >= 2
     red.broadcast_parameters(net)
     local = ddp.shard_batch(_make_batch(), rank, world)
     for _ in range(2):  # the second step re-uses the slot views
@@ -91,6 +93,133 @@ def _worker_flat(rank, world, port, ret):
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))
     ret[rank] = [p.grad.clone() for p in net.parameters()] + [p.detach().clone() for p in net.parameters()]
     dist.destroy_process_group()
+
+
+def _tiny3d():
+    import yolov10_3d_amd as y3d
+    cfg = y3d.yaml_model_load("yolov10s_3D.yaml")
+    cfg.update(scales={"n": [0.33, 0.125, 1024]}, scale="n",
+               channels={k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")})
+    return y3d.YOLOv10_3DDetectionModel(cfg)
+
+
+def _fake_grad(p, i, rank):
+    """deterministic per (parameter, rank) gradient"""
+    g = torch.Generator().manual_seed(1000 * i + rank)
+    return torch.randn(p.shape, generator=g)
+
+
+def _worker_real_model(rank, world, port, ret, overlap):
+    """the REAL tiny 3D model's parameter set: stacked head storage (restack), broadcast from rank 0, bucketed reduce"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddp.init("gloo")
+    torch.manual_seed(100 + rank)  # ranks start from DIFFERENT weights and BatchNorm statistics
+    model = _tiny3d()
+    for b in model.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.running_mean.uniform_(-1, 1)
+    head = model.model[-1]
+    head.restack()  # bench.py order: stack first, then build the reducer, then broadcast
+    ptrs = {id(p): p.data_ptr() for p in model.parameters()}
+    red = _CpuReducer(model.parameters(), bucket_mb=0.25, overlap=overlap)
+    red.broadcast_parameters(model)
+    head.restack()
+    assert all(p.data_ptr() == ptrs[id(p)] for p in model.parameters()), "broadcast / restack moved a parameter"
+    # the stacked views still alias the per-branch parameters after the broadcast
+    _, _, s1, s2, _, _ = head._stacks(0)
+    w, gm, bt, rm, rv = s1.tensors()
+    off = 0
+    for c in s1.convs:
+        n = c.conv.weight.numel()
+        assert c.conv.weight.data_ptr() == w.data_ptr() + 4 * off and torch.equal(c.conv.weight.detach().reshape(-1), w.reshape(-1)[off:off + n])
+        off += n
+    assert len(red.params) == len(list(model.parameters())) and len(red.buckets) >= 4
+    assert red.params[0] is list(model.parameters())[-1], "layout is head-first (reverse registration order)"
+    plist = list(model.parameters())
+    index = {id(p): i for i, p in enumerate(plist)}
+    skip = {id(plist[3])}  # one parameter without a gradient (an unused detect level): its slot stays zero on every rank
+    for step in range(2):
+        for p in plist:
+            p.grad = None
+        # a backward pass stand-in that fires the post-accumulate hooks in reverse registration order (head first)
+        loss = sum((p * _fake_grad(p, index[id(p)], rank + 10 * step)).sum() for p in plist if id(p) not in skip)
+        loss.backward()
+        flat = red.finish()
+        assert plist[3].grad is None
+        assert all(p.grad.data_ptr() == red.views[i].data_ptr() for i, p in enumerate(red.params) if p.grad is not None)
+    ret[rank] = {"grads": [None if p.grad is None else p.grad.clone() for p in plist], "params": [p.detach().clone() for p in plist],
+                 "buffers": [b.clone() for b in model.buffers()], "nbuckets": len(red.buckets)}
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_world2_gloo_reducer_on_real_tiny_model(overlap):
+    """W5 of round 1: the N>1 path of bench.py on the real model's ~570 re-pointed / stacked parameters — restack() +
+    broadcast_parameters order, head-first bucket plan, hook-driven in-order launches (overlap) and the after-backward path"""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_real_model, args=(world, port, ret, overlap), nprocs=world, join=True)
+    torch.manual_seed(100)
+    ref = _tiny3d()  # rank 0's initial model
+    for b in ref.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.running_mean.uniform_(-1, 1)
+    plist = list(ref.parameters())
+    for r in range(world):
+        for a, b in zip(ret[r]["params"], plist):
+            assert torch.equal(a, b.detach()), "parameters were not broadcast from rank 0"
+        for a, b in zip(ret[r]["buffers"], ref.buffers()):
+            assert torch.equal(a, b)
+        for i, (g, p) in enumerate(zip(ret[r]["grads"], plist)):
+            if i == 3:
+                assert g is None
+                continue
+            want = _fake_grad(p, i, 10) + _fake_grad(p, i, 11)  # step 1: SUM over the two ranks
+            assert torch.allclose(g, want, rtol=1e-6, atol=1e-6), i
+
+
+def test_shard_batch_decides_by_key_not_by_shape():
+    """exactly nc = 3 boxes next to the (3, 3) mean_sizes, and as many boxes as images"""
+    B = 4
+    for nbox in (3, B):
+        bi = torch.tensor([0.0, 2.0, 3.0] if nbox == 3 else [0.0, 1.0, 2.0, 3.0])
+        full = {"img": torch.rand(B, 3, 8, 8), "batch_idx": bi, "cls": torch.arange(nbox).float().view(-1, 1), "bboxes": torch.rand(nbox, 4),
+                "depth": torch.arange(nbox).float(), "calib": torch.arange(B * 6).float().view(B, 6),
+                "mean_sizes": torch.arange(9).float().view(3, 3), "mixed": torch.zeros(B, dtype=torch.uint8), "im_file": [f"{i}.png" for i in range(B)]}
+        seen = 0
+        for r in range(2):
+            loc = ddp.shard_batch(full, r, 2)
+            assert torch.equal(loc["mean_sizes"], full["mean_sizes"])           # replicated, never sliced
+            assert torch.equal(loc["calib"], full["calib"][2 * r:2 * r + 2])     # per image
+            assert loc["im_file"] == full["im_file"][2 * r:2 * r + 2]
+            sel = (bi >= 2 * r) & (bi < 2 * r + 2)
+            assert torch.equal(loc["depth"], full["depth"][sel]) and torch.equal(loc["batch_idx"], bi[sel] - 2 * r)
+            seen += loc["depth"].numel()
+        assert seen == nbox
+    with pytest.raises(KeyError):
+        ddp.shard_batch({**full, "mystery": torch.zeros(B)}, 0, 2)
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run ... bench.py --gpus N` as a CHILD
+    process (reference scheme: utils/dist.py:55-65) and relays its exit code; under a launcher it does not spawn"""
+    import subprocess
+    import sys
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_world2_gloo_flat_reducer_matches_single_process():

@@ -298,10 +298,10 @@ def test_e2e_tiny2d_vs_reference_golden(dtype, tol):
         check(out["one2many"][0], g["y_eval_o2m"], 2e-3, "eval o2m")
 
 
-@pytest.mark.parametrize("name,S,B", [("yolov10m_3D.yaml", 320, 2), ("yolov10n_3D.yaml", 256, 2), ("yolov10l.yaml", 384, 1)])
+@pytest.mark.parametrize("name,S,B", [("yolov10s_3D.yaml", 320, 2), ("yolov10m_3D.yaml", 320, 2), ("yolov10n_3D.yaml", 256, 2), ("yolov10l.yaml", 384, 1)])
 def test_full_size_scales_vs_oracle(name, S, B):
-    """the shipped model yamls at full width (BASELINE configs[2]: M + 3D head with num_scales 2 and 3x3 / 1x1 branch kernels; N + 3D head;
-    configs[3]: L, 2D) on fresh seeded inputs: one training step of the HIP path (exact-fp32 mode) against the CPU oracle restatement
+    """the shipped model yamls at full width (BASELINE configs[1]: S + 3D head, the benchmark's model; configs[2]: M + 3D head with
+    num_scales 2 and 3x3 / 1x1 branch kernels; N + 3D head; configs[3]: L, 2D) on fresh seeded inputs: one training step of the HIP path (exact-fp32 mode) against the CPU oracle restatement
     with the same weights - loss items within 1e-3 and every parameter's gradient norm within 5e-3"""
     import yaml as _yaml
     import os as _os
@@ -548,6 +548,7 @@ def test_tal3d_hip_on_assigner_fixture_scale():
     from types import SimpleNamespace
     from yolov10_3d_amd import loss as PL
     import bench
+    import torch_assigners as TA
     y3d.set_compute_dtype(torch.float32)
     torch.manual_seed(5)
     B, nc = 8, 3
@@ -572,12 +573,16 @@ def test_tal3d_hip_on_assigner_fixture_scale():
         anc, st = PL.make_anchors(shapes, strides, DEV)
         rows = torch.cat([batch[k].float().view(batch[k].shape[0], -1) for k in
                           ("batch_idx", "cls", "bboxes", "center_2d", "size_2d", "center_3d", "size_3d", "depth", "heading_bin", "heading_res")], 1)
-        gpad = PL._pad_targets(rows, B, 17, torch.tensor([640.0, 640.0, 640.0, 640.0], device=DEV))
+        gpad = TA.pad_targets_torch(rows, B, 17, torch.tensor([640.0, 640.0, 640.0, 640.0], device=DEV))
+        # the HIP padding kernel (fixed capacity, device-side count) holds the same rows, bit for bit, and zeros behind them
+        ghip, n_used = PL.pad_targets(rows, B, 17, (640.0, 640.0))
+        nm = gpad.shape[1]
+        assert int(n_used) == nm and torch.equal(ghip[:, :nm], gpad) and not ghip[:, nm:].any()
         gts = gpad.split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)
         mask_gt = (gts[1].sum(2, keepdim=True) > 0).float()
         cen = anc + o2d
         pb = torch.cat((cen - s2d / 2, cen + s2d / 2), -1) * st
-        asg = PL.TaskAlignedAssigner3d(topk=topk, num_classes=nc, alpha=0.5, beta=1.0, gamma=1.0)
+        asg = TA.TaskAlignedAssigner3d(topk=topk, num_classes=nc, alpha=0.5, beta=1.0, gamma=1.0)
         targets, fg_t, gi_t, _, _ = asg(sc.sigmoid(), pb, torch.cat((o3d, s3d, hd, dep, dun), -1), anc * st, gts, mask_gt, st,
                                         batch["calib"], batch["mean_sizes"])
         assert int(fg_t.sum()) > 0

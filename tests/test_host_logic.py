@@ -1,5 +1,5 @@
-"""CPU: host-side logic of the package (yaml -> model, state_dict layout, loss/assigner bodies that are
-expressed with torch device ops) against the reference's golden vectors."""
+"""CPU: host-side logic of the package (yaml -> model, state_dict layout) and the test-only torch formulations of the assigners
+(tests/torch_assigners.py, the comparators of the HIP kernels at bench scale) against the reference's golden vectors."""
 import pytest
 import torch
 
@@ -8,6 +8,7 @@ from conftest import load_golden
 import yolov10_3d_amd as y3d
 from yolov10_3d_amd import loss as PL
 from oracle import restate as RS
+import torch_assigners as TA
 
 
 def close(a, b, rtol=1e-4, atol=2e-5):
@@ -42,7 +43,7 @@ def test_state_dict_keys_match_reference_fixture():
 def test_assigner3d_cpu(topk):
     g = load_golden(f"tal3d_topk{topk}")
     gts = g["gt"].split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)
-    asg = PL.TaskAlignedAssigner3d(topk=topk, num_classes=3, alpha=0.5, beta=1.0, gamma=1.0)
+    asg = TA.TaskAlignedAssigner3d(topk=topk, num_classes=3, alpha=0.5, beta=1.0, gamma=1.0)
     targets, fg, gi, pk, gk = asg(g["pd_scores"], g["pd_bboxes"], g["pd_3d"], g["anc"] * g["stride"], gts, g["mask_gt"], g["stride"],
                                   g["calib"], g["mean_sizes"])
     assert torch.equal(fg, g["fg_mask"].bool()) and torch.equal(gi, g["target_gt_idx"].long())
@@ -55,7 +56,7 @@ def test_assigner3d_cpu(topk):
 def test_assigner2d_cpu(topk):
     g = load_golden(f"tal2d_topk{topk}")
     gl, gb = g["gt"].split((1, 4), 2)
-    asg = PL.TaskAlignedAssigner(topk=topk, num_classes=80, alpha=0.5, beta=6.0)
+    asg = TA.TaskAlignedAssigner(topk=topk, num_classes=80, alpha=0.5, beta=6.0)
     tl, tb, ts, fg, gi = asg(g["pd_scores"], g["pd_bboxes"], g["anc"] * g["stride"], gl, gb, g["mask_gt"])
     assert torch.equal(fg, g["fg_mask"].bool()) and torch.equal(gi, g["target_gt_idx"].long())
     close(ts, g["target_scores"], atol=1e-6)
@@ -129,3 +130,65 @@ def test_fold_conv_bn_matches_reference_fixture():
     w, b = y3d.tasks.fuse_conv_and_bn(g["w"], g["gamma"], g["beta"], g["mean"], g["var"])
     close(w, g["w_folded"])
     close(b, g["b_folded"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# initialisation constants against the reference-minted fixture (oracle/make_golden_init.py)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nl", [3, 2])
+def test_bias_init_3d_matches_reference_fixture(nl):
+    from yolov10_3d_amd import modules as M
+    g = load_golden("bias_init")[f"head3d_nl{nl}"]
+    chan = {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    torch.manual_seed(0)
+    hd = M.v10Detect3d(3, (16, 32, 64), False, chan, False, False, False, False, nl, False, False, 3, 3)
+    hd.stride = torch.tensor([8.0, 16.0, 32.0][:nl])
+    hd.bias_init()
+    for name in ("cls", "o2d", "s2d", "o3d", "s3d", "dep"):
+        for i in range(nl):
+            assert torch.equal(getattr(hd, name)[i][-1].bias.detach(), g[f"{name}/{i}/bias"]), f"{name}[{i}] bias"
+    deps, ranges = M.v10Detect3d.DEPTH_PRIOR[nl]
+    for i in range(nl):
+        # re-drawn projection weights: same distribution as the reference's draw (its min / max / mean / std are in the fixture)
+        w = hd.dep[i][-1].weight.detach()
+        lo, hi = ranges[i]
+        ref = g[f"dep/{i}/weight_stats"]
+        assert lo <= float(w.min()) and float(w.max()) <= hi and lo <= float(ref[0]) and float(ref[1]) <= hi
+        assert 0.6 < float(w.std()) / float(ref[3]) < 1.6
+        w = hd.s3d[i][-1].weight.detach()
+        ref = g[f"s3d/{i}/weight_stats"]
+        assert 0.6 < float(w.std()) / float(ref[3]) < 1.6 and abs(float(w.mean())) < 0.03
+    # the one-to-one set aliases the named branches; the one-to-many set restarts as its copy (head.py:869-870)
+    assert int(g["o2m_equals_o2o"]) == 1
+    assert hd.o2o_heads[0] is hd.cls and hd.o2o_heads[6] is hd.dep
+    for a, b in zip(hd.o2o_heads.state_dict().values(), hd.o2m_heads.state_dict().values()):
+        assert torch.equal(a, b)
+    assert hd.o2m_heads[0][0][0].conv.weight.data_ptr() != hd.cls[0][0].conv.weight.data_ptr()
+
+
+def test_bias_init_2d_and_initialize_weights_match_reference_fixture():
+    from yolov10_3d_amd import modules as M
+    g = load_golden("bias_init")
+    torch.manual_seed(0)
+    h2 = M.v10Detect(80, (16, 32, 64))
+    h2.stride = torch.tensor([8.0, 16.0, 32.0])
+    h2.bias_init()
+    for i in range(3):
+        for name in ("cv2", "cv3", "one2one_cv2", "one2one_cv3"):
+            assert torch.equal(getattr(h2, name)[i][-1].bias.detach(), g["head2d"][f"{name}/{i}/bias"]), f"{name}[{i}]"
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.SiLU())
+    y3d.tasks.initialize_weights(m)
+    eps, mom = [float(v) for v in g["initialize_weights"]["bn_eps_momentum"]]
+    assert (m[1].eps, m[1].momentum) == (eps, mom) and int(m[2].inplace) == int(g["initialize_weights"]["silu_inplace"])
+    # a built model carries them on every BatchNorm (tasks.DetectionModel.__init__ calls initialize_weights)
+    cfg = y3d.yaml_model_load("yolov10s_3D.yaml")
+    cfg.update(scales={"n": [0.33, 0.125, 1024]}, scale="n",
+               channels={k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")})
+    model = y3d.YOLOv10_3DDetectionModel(cfg)
+    bns = [b for b in model.modules() if isinstance(b, torch.nn.BatchNorm2d)]
+    assert bns and all((b.eps, b.momentum) == (eps, mom) for b in bns)
+    # ... and its head went through bias_init with the model's strides (tasks.py: DetectionModel.__init__)
+    g3 = g["head3d_nl3"]
+    head = model.model[-1]
+    for i in range(3):
+        assert torch.equal(head.cls[i][-1].bias.detach()[:3], g3[f"cls/{i}/bias"]) and torch.equal(head.dep[i][-1].bias.detach(), g3[f"dep/{i}/bias"])

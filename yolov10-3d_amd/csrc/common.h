@@ -113,4 +113,13 @@ void y3d_set_error(const char* fmt, ...);
     }                                                        \
   } while (0)
 
+#define Y3D_HIP(call)                                                 \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) {                                           \
+      y3d_set_error("%s: %s", #call, hipGetErrorString(e_));          \
+      return Y3D_ERR_HIP;                                             \
+    }                                                                 \
+  } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

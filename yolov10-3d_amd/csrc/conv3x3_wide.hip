@@ -121,7 +121,8 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #define TRC(i)
 #endif
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // `wave` and everything derived from it is wave-uniform: scalar registers (the compiler cannot prove threadIdx.x >> 6 uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
   const int ltid = tid & (LH - 1);
   const int wimg = wp / WPI, wrow0 = (wp % WPI) * 8;
@@ -369,9 +370,16 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     // ---- epilogue: this lane holds channels cl(h) .. cl(h)+7, h = 0 / 1, of pixels (wrow0 + pt, lp) of image b0 + wimg.  The two
     // 64-byte halves of a pixel's 128-byte line are stored back to back: written a pass apart (8 stores later) the L2 had evicted
     // the half-dirty line in between and re-filled it for the second half (PMC: WRITE_SIZE 1.36x the tensor, FETCH_SIZE up too) ------
+    // Lane-derived epilogue values are recomputed HERE from the one lane id the DMA issue keeps live anyway (opaque copy): carried
+    // through the K loop they were spilled to scratch, and a scratch reload is followed by s_waitcnt vmcnt(0) - the drain of the next
+    // tile's DMA prefetch that this kernel is built to avoid
+    int el = ltid;
+    asm volatile("" : "+v"(el));
+    const int e_lp = el & 15, e_lq = (el >> 4) & 3;
+    const int e_tid = (HROLE ? 0 : LH) + el;
     const int bb = cur.b0 + wimg;
-    const bool xok = cur.x0 + lp < p.W;
-    const int cl0 = wc * 64 + lq * 8;
+    const bool xok = cur.x0 + e_lp < p.W;
+    const int cl0 = wc * 64 + e_lq * 8;
     bool cok[2];
     float ssum[2][8], ssq[2][8], sv[2][8], hv[2][8];
 #pragma unroll
@@ -390,7 +398,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
       const int yy = cur.y0 + wrow0 + pt;
-      bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
+      bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + e_lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float v[8];
@@ -421,7 +429,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         for (int i = 0; i < 8; ++i) {
           float s = wave_xor_sum16(ssum[h][i]);
           float q2 = wave_xor_sum16(ssq[h][i]);
-          if (lp == i) {
+          if (e_lp == i) {
             red[(wp * 128 + cl0 + h * 32 + i) * 2 + 0] = s;
             red[(wp * 128 + cl0 + h * 32 + i) * 2 + 1] = q2;
           }
@@ -430,8 +438,8 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     if (EPI == 0 && p.part) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // not __syncthreads(): its fence would drain the DMA prefetch of the next tile
       __builtin_amdgcn_s_barrier();
-      if (tid < 128 * NB) {
-        const int img = tid >> 7, ch = tid & 127;
+      if (e_tid < 128 * NB) {
+        const int img = e_tid >> 7, ch = e_tid & 127;
         if (cur.c0 + ch < p.Cn && cur.b0 + img < p.B) {
           float s = 0.f, q2 = 0.f;
 #pragma unroll

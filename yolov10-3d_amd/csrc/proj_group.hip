@@ -150,8 +150,13 @@ __global__ __launch_bounds__(256, 2) void projg_bwd_weight_kernel(ProjG g, const
         for (int j = 0; j < CE; ++j) { bsc[j] = bn.scale[g.xoff[br] + c + j]; bsh[j] = bn.shift[g.xoff[br] + c + j]; }
       }
       // dy values of one pixel for this pass (clamped index: lanes past the branch's last output re-read it, never past the row)
-      auto dload = [&](long px, float* d) {
-        const T* drow = dp + px * dsw + o0;
+      // pixel indices are block-relative 32-bit ints on scalar base pointers (64-bit per-lane addresses for four pixels in flight
+      // pushed the kernel to 12 B of scratch)
+      const T* dpb = dp + pbeg * dsw;
+      const T* xpb = xp + pbeg * xsw + c;
+      const int dswi = (int)dsw, xswi = (int)xsw, npx = (int)(pend - pbeg);
+      auto dload = [&](int px, float* d) {
+        const T* drow = dpb + px * dswi + o0;
 #pragma unroll
         for (int o = 0; o < OG; ++o) d[o] = TT<T>::ld(drow + (o < no ? o : no - 1));
       };
@@ -173,10 +178,10 @@ __global__ __launch_bounds__(256, 2) void projg_bwd_weight_kernel(ProjG g, const
             for (int j = 0; j < CE; ++j) acc[o][j] += d[o] * v[j];
           }
       };
-      long px = pbeg + pt;
-      for (; px + 3 * PT < pend; px += 4 * PT) {  // four pixels in flight, x chunks AND dy values: the loop is latency-bound otherwise
-        const uint4 x0 = *(const uint4*)(xp + px * xsw + c), x1 = *(const uint4*)(xp + (px + PT) * xsw + c);
-        const uint4 x2 = *(const uint4*)(xp + (px + 2 * PT) * xsw + c), x3 = *(const uint4*)(xp + (px + 3 * PT) * xsw + c);
+      int px = pt;
+      for (; px + 3 * PT < npx; px += 4 * PT) {  // four pixels in flight, x chunks AND dy values: the loop is latency-bound otherwise
+        const uint4 x0 = *(const uint4*)(xpb + px * xswi), x1 = *(const uint4*)(xpb + (px + PT) * xswi);
+        const uint4 x2 = *(const uint4*)(xpb + (px + 2 * PT) * xswi), x3 = *(const uint4*)(xpb + (px + 3 * PT) * xswi);
         float d0[OG], d1[OG], d2[OG], d3[OG];
         dload(px, d0); dload(px + PT, d1); dload(px + 2 * PT, d2); dload(px + 3 * PT, d3);
         one(x0, d0);
@@ -184,10 +189,10 @@ __global__ __launch_bounds__(256, 2) void projg_bwd_weight_kernel(ProjG g, const
         one(x2, d2);
         one(x3, d3);
       }
-      for (; px < pend; px += PT) {
+      for (; px < npx; px += PT) {
         float d0[OG];
         dload(px, d0);
-        one(*(const uint4*)(xp + px * xsw + c), d0);
+        one(*(const uint4*)(xpb + px * xswi), d0);
       }
     }
     // fold the block's 32 pixel rows: the 8 rows of a wave by VALU lane swaps (bf16 layout: lane = (row % 8) * 8 + chunk), the 4 waves
@@ -317,6 +322,7 @@ static int proj_group_bwd_weight_impl(int dtype, int nb, int cin, const void* x,
   if (ctot < 0) return ctot;
   int nblk = y3d_proj_group_blocks(P);
   int ppb = (int)((P + nblk - 1) / nblk);
+  Y3D_CHECK((long)ppb * (xsw > dsw ? xsw : dsw) < (1L << 31), "proj_group_bwd_weight: a block's pixel range exceeds 32-bit element offsets");
   dim3 grid(nblk, cdiv(cin, 64), nb);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(projg_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const bf16_t*)x, (long)xsw, (const bf16_t*)dy, (long)dsw, slab, bslab, (long)P, ctot, ppb, bn);

@@ -36,6 +36,15 @@ __device__ __forceinline__ const T* anchor_ptr(const Levels& L, int b, int a, fl
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
+// GT rows in use: the padded target tensor has `n` rows per image (its capacity); `n_used` (device, may be null) holds the largest
+// per-image box count, written by y3d_pad_targets — the host never learns it, so the step has no host sync (the reference's
+// `counts.max()` sizes the tensor on the host, loss.py:801-803).  Rows in [n_used, n) are all-zero padding in every image.
+__device__ __forceinline__ int rows_used(const int* __restrict__ n_used, int n) {
+  if (!n_used) return n;
+  int v = *n_used;
+  return v < n ? v : n;
+}
+
 // utils/metrics.py:78-134 bbox_iou(xywh=False, CIoU=True), box1 = gt, box2 = prediction
 __device__ __forceinline__ float ciou_f(const float* g, float x21, float y21, float x22, float y22) {
   const float eps = 1e-7f;
@@ -60,13 +69,14 @@ __device__ __forceinline__ float ciou_f(const float* g, float x21, float y21, fl
 
 // one block per (b, g): k passes of arg-max with (value desc, index asc) order; cand[b][g][j] = anchor index or -1
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ align, const float* __restrict__ rec, int* __restrict__ cand,
-                                                   Levels L, int n, int k) {
+                                                   Levels L, int n, int k, const int* __restrict__ n_used) {
   __shared__ float sv[256];
   __shared__ int si[256];
   __shared__ int chosen[16];
   const int bg = blockIdx.x, b = bg / n;
   const float* r = rec + (long)bg * GTW;
   int* out = cand + (long)bg * k;
+  if (bg - b * n >= rows_used(n_used, n)) return;  // never read: resolve_kernel stops at the same bound
   if (r[G_VALID] == 0.f) {
     if (threadIdx.x < k) out[threadIdx.x] = -1;
     return;
@@ -117,12 +127,13 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ ali
 // per anchor: how many GTs selected it; the winner; per-GT normalisers by atomicMax on the (non-negative) float bits
 __global__ void resolve_kernel(const int* __restrict__ cand, const float* __restrict__ align, const float* __restrict__ sim,
                                unsigned char* __restrict__ fg, int* __restrict__ gt_idx, unsigned* __restrict__ pa, unsigned* __restrict__ po,
-                               int B, int n, int A, int k) {
+                               int B, int n, int A, int k, const int* __restrict__ n_used) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * A) return;
   int b = (int)(i / A), a = (int)(i - (long)b * A);
   int cnt = 0, gsel = 0;
-  for (int g = 0; g < n; ++g) {
+  const int ne = rows_used(n_used, n);  // rows >= ne are padding in every image: they select nothing and their sim is 0
+  for (int g = 0; g < ne; ++g) {
     const int* c = cand + ((long)b * n + g) * k;
     bool hit = false;
     for (int j = 0; j < k; ++j) hit |= (c[j] == a);
@@ -130,7 +141,7 @@ __global__ void resolve_kernel(const int* __restrict__ cand, const float* __rest
   }
   if (cnt > 1) {  // tal.py:741-748: arg-max of `overlaps` (= similarities) over ALL gts, first maximum
     float bv = -1.f;
-    for (int g = 0; g < n; ++g) {
+    for (int g = 0; g < ne; ++g) {
       float v = sim[((long)b * n + g) * A + a];
       if (v > bv) { bv = v; gsel = g; }
     }

@@ -50,7 +50,8 @@ __device__ __forceinline__ float dfl_expect(const T* z, float* prob) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void metric2d_kernel(Levels L, const float* __restrict__ rec, float* __restrict__ align,
-                                                       float* __restrict__ ovl, int n, float alpha, float beta) {
+                                                       float* __restrict__ ovl, int n, float alpha, float beta,
+                                                       const int* __restrict__ n_used) {
   extern __shared__ float sg[];
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < n * GTW; i += blockDim.x) sg[i] = rec[(long)b * n * GTW + i];
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void metric2d_kernel(Levels L, const float* __
         db = dfl_expect<T>(p + 3 * RM, nullptr);
   float bx1 = (ax - dl) * st, by1 = (ay - dtp) * st, bx2 = (ax + dr) * st, by2 = (ay + db) * st;
   float apx = ax * st, apy = ay * st;
-  for (int g = 0; g < n; ++g) {
+  const int ne = rows_used(n_used, n);
+  for (int g = 0; g < ne; ++g) {
     const float* r = sg + g * GTW;
     float al = 0.f, ov = 0.f;
     if (r[G_VALID] != 0.f) {
@@ -276,7 +278,7 @@ extern "C" {
 
 int y3d_tal2d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
                      int B, int nc, const float* gt, int n, int topk, float alpha, float beta, float* scratch, uint8_t* fg_mask,
-                     int* target_gt_idx, float* target_scores, float* scal, void* stream) {
+                     int* target_gt_idx, float* target_scores, float* scal, const int* n_used, void* stream) {
   Levels L;
   if (fill2d(L, dtype, nl, maps, psw, nullptr, nullptr, H, W, strides, B, nc)) return Y3D_ERR_INVALID;
   Y3D_CHECK(n >= 1 && n <= 64, "tal2d_assign: 1..64 ground-truth boxes per image (got %d)", n);
@@ -290,15 +292,15 @@ int y3d_tal2d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   unsigned* pa = (unsigned*)(cand + (long)B * n * topk);
   unsigned* po = pa + (long)B * n;
   float* part = (float*)(po + (long)B * n);
-  (void)hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st);
+  Y3D_HIP(hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st));
   hipLaunchKernelGGL(gt2d_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, rec, B, n, nc);
   dim3 gm(cdiv(A, 256), B);
   size_t sm = (size_t)n * GTW * sizeof(float);
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric2d_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, align, ovl, n, alpha, beta);
-  else hipLaunchKernelGGL(metric2d_kernel<float>, gm, dim3(256), sm, st, L, rec, align, ovl, n, alpha, beta);
-  hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), 0, st, align, rec, cand, L, n, topk);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric2d_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, align, ovl, n, alpha, beta, n_used);
+  else hipLaunchKernelGGL(metric2d_kernel<float>, gm, dim3(256), sm, st, L, rec, align, ovl, n, alpha, beta, n_used);
+  hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), 0, st, align, rec, cand, L, n, topk, n_used);
   int nblk = cdiv((long)B * A, 256);
-  hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, ovl, fg_mask, target_gt_idx, pa, po, B, n, A, topk);
+  hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, ovl, fg_mask, target_gt_idx, pa, po, B, n, A, topk, n_used);
   hipLaunchKernelGGL(scores_kernel, dim3(nblk), dim3(256), 0, st, fg_mask, target_gt_idx, align, rec, pa, po, target_scores, part, B, n, A, nc, 1e-9f);
   hipLaunchKernelGGL(scal_kernel, dim3(1), dim3(64), 0, st, part, nblk, scal);
   Y3D_LAUNCH_CHECK();

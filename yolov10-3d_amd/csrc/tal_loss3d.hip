@@ -72,7 +72,8 @@ __global__ void gt_prep_kernel(const float* __restrict__ gt, const float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __restrict__ rec, const float* __restrict__ calib,
                                                      const float* __restrict__ mean_sizes, float* __restrict__ align,
-                                                     float* __restrict__ sim, int n, float alpha, float beta, float gamma) {
+                                                     float* __restrict__ sim, int n, float alpha, float beta, float gamma,
+                                                     const int* __restrict__ n_used) {
   extern __shared__ float sg[];  // [n][GTW]
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < n * GTW; i += blockDim.x) sg[i] = rec[(long)b * n * GTW + i];
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __re
   float dep = TT<T>::ld(p + nc + 33);
   float kp[24];
   keypoints(c3x, c3y, dep, sh, sw, sl, hb, hres, calib + b * 6, kp);
-  for (int g = 0; g < n; ++g) {
+  const int ne = rows_used(n_used, n);
+  for (int g = 0; g < ne; ++g) {
     const float* r = sg + g * GTW;
     float al = 0.f, sm = 0.f;
     if (r[G_VALID] != 0.f) {
@@ -132,10 +134,48 @@ __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __re
   }
 }
 
+// utils/loss.py:795-810 `preprocess`: ragged per-box rows [batch_idx | cls | xywh in [0,1] | ...] -> (B, cap, width) zero-padded per image
+// in order of appearance, boxes scaled to pixels and converted to xyxy; *n_used = largest per-image box count (device side: the
+// reference sizes the tensor with a host-side counts.max()).  One block per image.
+__global__ __launch_bounds__(256) void pad_targets_kernel(const float* __restrict__ rows, int nbox, int width, float* __restrict__ out, int cap,
+                                                          float sx, float sy, int* __restrict__ n_used) {
+  __shared__ int smax[256];
+  const int b = blockIdx.x, rw = width + 1;
+  float* o = out + (long)b * cap * width;
+  for (int i = threadIdx.x; i < cap * width; i += 256) o[i] = 0.f;
+  __syncthreads();
+  int mx = 0;
+  for (int i = threadIdx.x; i < nbox; i += 256) {
+    if ((int)rows[(long)i * rw] != b) continue;
+    int pos = 0;
+    for (int j = 0; j < i; ++j) pos += ((int)rows[(long)j * rw] == b);
+    mx = max(mx, pos + 1);
+    if (pos >= cap) continue;
+    const float* r = rows + (long)i * rw + 1;
+    float* d = o + (long)pos * width;
+    d[0] = r[0];
+    float x = r[1] * sx, y = r[2] * sy, w = r[3] * sx, h = r[4] * sy;
+    d[1] = x - w / 2.f;
+    d[2] = y - h / 2.f;
+    d[3] = x + w / 2.f;
+    d[4] = y + h / 2.f;
+    for (int c = 5; c < width; ++c) d[c] = r[c];
+  }
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && smax[0] > 0) atomicMax(n_used, smax[0]);
+}
+
 struct LossW { float loss2d, cls, depth, offset3d, size3d, heading; };
 
 // per anchor: six loss terms (already divided by the normalisers) and the gradient of their sum times `gscale` wrt the 38 logits
-template <typename T>
+// NC = number of classes as a template parameter: the gradient row gr[] is indexed by nc + j, and with a run-time nc the array
+// lived in scratch (176 B per lane)
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void loss_kernel(Levels L, const unsigned char* __restrict__ fg, const int* __restrict__ gt_idx,
                                                    const float* __restrict__ tscores, const float* __restrict__ gt,
                                                    const float* __restrict__ scal, LossW w, float gscale, float* __restrict__ part,
@@ -151,12 +191,13 @@ __global__ __launch_bounds__(256) void loss_kernel(Levels L, const unsigned char
     int r = a - L.a0[lvl];
     int hy = r / L.W[lvl], hx = r - hy * L.W[lvl];
     T* gp = (T*)L.grad[lvl] + (((long)b * L.H[lvl] + hy) * L.W[lvl] + hx) * L.gsw[lvl];
-    const int nc = L.nc;
+    constexpr int nc = NC;
     const float tss = scal[0], nfg = scal[1];
     float gr[40];
 #pragma unroll
     for (int c = 0; c < 40; ++c) gr[c] = 0.f;
     // classification: BCE with logits against the normalised target scores, dense (loss.py:888)
+#pragma unroll
     for (int c = 0; c < nc; ++c) {
       float x = TT<T>::ld(p + c), t = tscores[i * nc + c];
       float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
@@ -213,12 +254,18 @@ __global__ __launch_bounds__(256) void loss_kernel(Levels L, const unsigned char
       for (int j = 0; j < 12; ++j) se += expf(hv[j] - mx);
       float lse = mx + logf(se);
       float pr = TT<T>::ld(p + nc + 21 + tb), tr = g[16];
-      l[5] = (lse - hv[tb] + fabsf(pr - tr)) / tss * w.heading;
+      float hvt = hv[0];
+#pragma unroll
+      for (int j = 1; j < 12; ++j) hvt = j == tb ? hv[j] : hvt;
+      l[5] = (lse - hvt + fabsf(pr - tr)) / tss * w.heading;
 #pragma unroll
       for (int j = 0; j < 12; ++j) gr[nc + 9 + j] = (expf(hv[j] - lse) - (j == tb ? 1.f : 0.f)) / tss * w.heading;
-      gr[nc + 21 + tb] = (pr > tr ? 1.f : (pr < tr ? -1.f : 0.f)) / tss * w.heading;
+      const float gres = (pr > tr ? 1.f : (pr < tr ? -1.f : 0.f)) / tss * w.heading;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) gr[nc + 21 + j] = j == tb ? gres : 0.f;  // static indices: a run-time gr[.. + tb] puts gr[] in scratch
     }
-    for (int c = 0; c < L.no; ++c) TT<T>::st(gp + c, gr[c] * gscale);
+#pragma unroll
+    for (int c = 0; c < NC + 35; ++c) TT<T>::st(gp + c, gr[c] * gscale);
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) sh[j][threadIdx.x] = l[j];
@@ -280,10 +327,20 @@ static int fill_levels(Levels& L, int dtype, int nl, const void* const* maps, co
   return Y3D_OK;
 }
 
+int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, float scale_x, float scale_y, float* out, int* n_used,
+                    void* stream) {
+  Y3D_CHECK(B >= 1 && cap >= 1 && width >= 5 && nbox >= 0, "pad_targets: B, cap >= 1, width >= 5 (cls + box + ...)");
+  hipStream_t st = (hipStream_t)stream;
+  Y3D_HIP(hipMemsetAsync(n_used, 0, sizeof(int), st));
+  hipLaunchKernelGGL(pad_targets_kernel, dim3(B), dim3(256), 0, st, rows, nbox, width, out, cap, scale_x, scale_y, n_used);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
 int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
                      int B, int nc, const float* gt, int n, const float* calib, const float* mean_sizes, int topk, float alpha,
                      float beta, float gamma, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
-                     void* stream) {
+                     const int* n_used, void* stream) {
   Levels L;
   if (fill_levels(L, dtype, nl, maps, psw, nullptr, nullptr, H, W, strides, B, nc, nc + 35)) return Y3D_ERR_INVALID;
   Y3D_CHECK(n >= 1 && n <= 64, "tal3d_assign: 1..64 ground-truth boxes per image (got %d)", n);
@@ -297,15 +354,15 @@ int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   unsigned* pa = (unsigned*)(cand + (long)B * n * topk);
   unsigned* po = pa + (long)B * n;
   float* part = (float*)(po + (long)B * n);
-  hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st);
+  Y3D_HIP(hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st));
   hipLaunchKernelGGL(gt_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, calib, mean_sizes, rec, B, n, nc);
   dim3 gm(cdiv(A, 256), B);
   size_t sm = (size_t)n * GTW * sizeof(float);
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma);
-  else hipLaunchKernelGGL(metric_kernel<float>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma);
-  hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), 0, st, align, rec, cand, L, n, topk);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used);
+  else hipLaunchKernelGGL(metric_kernel<float>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used);
+  hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), 0, st, align, rec, cand, L, n, topk, n_used);
   int nblk = cdiv((long)B * A, 256);
-  hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, sim, fg_mask, target_gt_idx, pa, po, B, n, A, topk);
+  hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, sim, fg_mask, target_gt_idx, pa, po, B, n, A, topk, n_used);
   hipLaunchKernelGGL(scores_kernel, dim3(nblk), dim3(256), 0, st, fg_mask, target_gt_idx, align, rec, pa, po, target_scores, part, B, n, A, nc, 1e-9f);
   hipLaunchKernelGGL(scal_kernel, dim3(1), dim3(64), 0, st, part, nblk, scal);
   Y3D_LAUNCH_CHECK();
@@ -321,8 +378,11 @@ int y3d_loss3d(int dtype, int nl, const void* const* maps, const int64_t* psw, v
   LossW w{w_loss2d, w_cls, w_depth, w_offset3d, w_size3d, w_heading};
   hipStream_t st = (hipStream_t)stream;
   int nblk = cdiv((long)B * L.A, 256);
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(loss_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
-  else hipLaunchKernelGGL(loss_kernel<float>, dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n);
+#define Y3D_L3D(T, NC) hipLaunchKernelGGL((loss_kernel<T, NC>), dim3(nblk), dim3(256), 0, st, L, fg_mask, target_gt_idx, target_scores, gt, scal, w, grad_scale, partials, n)
+#define Y3D_L3D_NC(T) switch (nc) { case 1: Y3D_L3D(T, 1); break; case 2: Y3D_L3D(T, 2); break; case 3: Y3D_L3D(T, 3); break; case 4: Y3D_L3D(T, 4); break; default: Y3D_L3D(T, 5); break; }
+  if (dtype == Y3D_BF16) { Y3D_L3D_NC(bf16_t) } else { Y3D_L3D_NC(float) }
+#undef Y3D_L3D_NC
+#undef Y3D_L3D
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partials, nblk, items);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;

@@ -5,11 +5,13 @@ Reference behaviour restated (engine/trainer.py:225-236, 280, 292, 401-402; util
     model on its shard with its OWN BatchNorm statistics (no SyncBN) and its own assigner / loss;
   * the loss is `loss.sum() * local_batch` (utils/loss.py:900) and is multiplied by `world_size` before backward because the
     all-reduce AVERAGES gradients — so the update equals the single-process update on the global batch;
-  * the only collective on the data path is that gradient all-reduce (fp32, S-3D: 120 MB per step).
+  * the only collective on the data path is that gradient all-reduce (fp32, S-3D: 120 MB per step), which the reference's
+    DistributedDataParallel overlaps with the backward pass bucket by bucket (trainer.py:280).
 
 torch.distributed is the plumbing (backend "nccl" == RCCL on ROCm, "gloo" for the CPU tests).  Two reducers: `FlatGradReducer`
-(bench.py's N>1 path: one gather launch + one all-reduce of the flat 120 MB buffer per step) and `wrap` (torch
-DistributedDataParallel with buckets as views, kept as the drop-in for code that expects a DDP module).
+(bench.py's N>1 path: the flat fp32 gradient buffer laid out head-first and all-reduced bucket by bucket on a side stream while
+the backward of the earlier layers is still running) and `wrap` (torch DistributedDataParallel with buckets as views, kept as the
+drop-in for code that expects a DDP module).
 """
 from __future__ import annotations
 
@@ -17,6 +19,11 @@ import os
 
 import torch
 import torch.distributed as dist
+
+# keys of the collated batch dict (reference data/datasets/kitti.py:421-442, collate_fn :579-599)
+PER_BOX_KEYS = ("cls", "bboxes", "center_2d", "size_2d", "center_3d", "size_3d", "depth", "heading_bin", "heading_res")
+PER_IMAGE_KEYS = ("img", "calib", "mixed", "im_file", "ori_shape", "resized_shape", "ratio_pad", "info")
+REPLICATED_KEYS = ("mean_sizes",)
 
 
 def init(backend: str | None = None, device: torch.device | None = None):
@@ -34,8 +41,10 @@ def init(backend: str | None = None, device: torch.device | None = None):
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
-    """Rank's slice of a collated batch dict (schema: SURVEY §8b).  Per-image tensors (`img`, `calib`, `mixed`) are split
-    evenly; per-box tensors follow their `batch_idx`, which is re-based to the local image range."""
+    """Rank's slice of a collated batch dict (schema: SURVEY §8b).  The split is decided BY KEY, never by comparing leading
+    dimensions (a batch with as many boxes as images, or exactly `nc` boxes next to the (nc, 3) `mean_sizes`, is ambiguous by
+    shape): per-image entries are split evenly, per-box entries follow their `batch_idx` (re-based to the local image range),
+    `mean_sizes` is replicated.  Unknown tensor keys raise: silently mis-slicing a label tensor corrupts training."""
     if world == 1:
         return batch
     B = batch["img"].shape[0]
@@ -46,16 +55,20 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
     sel = (bi >= lo) & (bi < hi)
     out = {}
     for k, v in batch.items():
-        if not torch.is_tensor(v):
-            out[k] = v
-        elif k == "batch_idx":
+        if k.startswith("_y3d"):
+            continue  # per-step caches of the loss never travel between shards
+        if k == "batch_idx":
             out[k] = v[sel] - lo
-        elif v.dim() > 0 and v.shape[0] == bi.shape[0] and k not in ("img", "calib", "mixed"):
+        elif k in PER_BOX_KEYS:
+            assert v.shape[0] == bi.shape[0], f"shard_batch: per-box entry {k!r} has {v.shape[0]} rows for {bi.shape[0]} boxes"
             out[k] = v[sel]
-        elif v.dim() > 0 and v.shape[0] == B and k != "mean_sizes":
+        elif k in PER_IMAGE_KEYS:
+            assert len(v) == B, f"shard_batch: per-image entry {k!r} has {len(v)} rows for {B} images"
             out[k] = v[lo:hi]
-        else:
+        elif k in REPLICATED_KEYS or not torch.is_tensor(v):
             out[k] = v
+        else:
+            raise KeyError(f"shard_batch: do not know how to split batch entry {k!r} (add it to PER_BOX_KEYS / PER_IMAGE_KEYS / REPLICATED_KEYS)")
     return out
 
 
@@ -69,74 +82,190 @@ def wrap(model: torch.nn.Module, device_ids=None, bucket_cap_mb: float = 32.0):
 class FlatGradReducer:
     """Gradient all-reduce over ONE flat fp32 buffer (S-3D: 120 MB), the data-path collective of the reference's DDP.
 
-    After backward every gradient tensor is gathered into its slot of the flat buffer by one multi-tensor launch (`y3d_mt_copy`),
-    the buffer is all-reduced (SUM: with the unscaled local losses this equals the reference's `loss * world_size` + averaged
-    gradients, trainer.py:401-402), and `p.grad` is re-pointed at the slot, so the fused optimizer runs on stable pointers.
-    Why not torch DDP: its autograd hooks copy each of the ~570 gradient tensors into a bucket view one by one (+7 % step time
-    measured at one rank); the gather is one launch at HBM rate.  Parameters without a gradient (an unused detect level) keep
-    `grad = None` on every rank and their slots stay zero."""
+    Layout: parameters in REVERSE registration order, so the detect head (layer 23: 79 % of the bytes) comes first and
+    the buffer fills front to back as the backward pass runs.  The buffer is cut into buckets of about `bucket_mb`; a post-
+    accumulate hook on every parameter counts its bucket down, and as soon as a bucket AND all buckets before it are complete it is
+    gathered (one multi-tensor launch, `y3d_mt_copy`) and all-reduced on a side stream, behind an event recorded on the compute
+    stream at that point — the head buckets travel over xGMI while the backbone / neck backward is still computing.  Buckets are
+    always launched in index order, so every rank issues the same collectives in the same order.  `finish()` (after backward)
+    launches whatever is left (parameters without a gradient, e.g. an unused detect level, keep zero slots on every rank), makes
+    the compute stream wait for the collectives, and re-points `p.grad` at the slots, so the fused optimizer runs on stable
+    pointers.  SUM of the unscaled local losses' gradients equals the reference's `loss * world_size` + averaged gradients
+    (trainer.py:401-402).
+    Why not torch DDP: its autograd hooks copy each of the ~570 gradient tensors into a bucket view one by one (+17 % step time
+    measured at one rank); the gather is one launch per bucket at HBM rate.
+    `overlap=False` (env Y3D_DDP_OVERLAP=0): everything is gathered and reduced in `finish()`, after the backward."""
 
     CHUNK = 16384
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+    def __init__(self, params, bucket_mb: float = 32.0, overlap: bool | None = None, timing: bool = False):
+        seen, plist = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                plist.append(p)
+        if not plist:
             raise ValueError("FlatGradReducer: no parameters")
+        self.params = plist[::-1]  # head first
         dev = self.params[0].device
+        self.device = dev
         self.sizes = [p.numel() for p in self.params]
         self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
-        self.views, off = [], 0
+        self.views, self.offs, off = [], [], 0
         for p, n in zip(self.params, self.sizes):
             self.views.append(self.flat[off:off + n].view_as(p))
+            self.offs.append(off)
             off += n
-        self._active, self._tab = None, None
+        # buckets: contiguous parameter ranges [i0, i1) of about bucket_mb
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets, i0, acc = [], 0, 0
+        for i, n in enumerate(self.sizes):
+            acc += n
+            if acc >= cap or i == len(self.sizes) - 1:
+                self.buckets.append((i0, i + 1))
+                i0, acc = i + 1, 0
+        self.bucket_of = [0] * len(self.params)
+        for b, (a, e) in enumerate(self.buckets):
+            for i in range(a, e):
+                self.bucket_of[i] = b
+        if overlap is None:
+            overlap = os.environ.get("Y3D_DDP_OVERLAP", "1") != "0"
+        self.overlap = overlap
+        self.timing = timing
+        self.comm = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._tabs = {}
+        self._reset()
+        self._hooks = []
+        if overlap:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.last_times = None
+
+    # ---- per-step state ------------------------------------------------------------------------------------------
+    def _reset(self):
+        self._pending = [e - a for a, e in self.buckets]
+        self._ready = [False] * len(self.params)
+        self._next = 0
+        self._works = []
+        self._events = []
+        self._keep = []
+
+    def _make_hook(self, i):
+        def hook(p):
+            if self._ready[i]:
+                return  # accumulated twice in one backward (shared parameter): the bucket was counted once
+            self._ready[i] = True
+            b = self.bucket_of[i]
+            self._pending[b] -= 1
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
+        return hook
 
     def broadcast_parameters(self, module: torch.nn.Module):
         """rank 0's parameters and buffers to every rank (what DistributedDataParallel does when it wraps a module)"""
         if dist.is_initialized() and dist.get_world_size() > 1:
+            seen = set()
             for t in list(module.parameters()) + list(module.buffers()):
+                if id(t) in seen:
+                    continue
+                seen.add(id(t))
                 dist.broadcast(t.data, 0)
 
-    def _gather(self, active, grads):
+    # ---- gather + collective of one bucket -----------------------------------------------------------------------
+    def _gather(self, idx, grads):
+        """copy the gradient tensors `grads` of parameters `idx` into their slots (one HIP launch on the current stream)"""
         from ._lib import Y3DError, lib
         from . import ops
-        dev = self.flat.device
+        dev = self.device
         if dev.type != "cuda":
             raise Y3DError("FlatGradReducer needs gradients on a HIP device")
-        if self._active != active:
-            sizes = [self.sizes[i] for i in active]
+        key = tuple(idx)
+        tb = self._tabs.get(key)
+        if tb is None:
+            sizes = [self.sizes[i] for i in idx]
             ct, co = [], []
             for t, n in enumerate(sizes):
                 for c in range((n + self.CHUNK - 1) // self.CHUNK):
                     ct.append(t)
                     co.append(c)
-            self._tab = {"sizes": torch.tensor(sizes, dtype=torch.int64, device=dev), "ct": torch.tensor(ct, dtype=torch.int32, device=dev),
-                         "co": torch.tensor(co, dtype=torch.int32, device=dev), "n": len(ct),
-                         "dst": torch.tensor([self.views[i].data_ptr() for i in active], dtype=torch.int64, device=dev)}
-            self._active = active
-        tb = self._tab
-        if tb.get("up") is None:
             from .optim import PtrUploader
-            tb["up"] = PtrUploader(len(active), dev)
+            tb = {"sizes": torch.tensor(sizes, dtype=torch.int64, device=dev), "ct": torch.tensor(ct, dtype=torch.int32, device=dev),
+                  "co": torch.tensor(co, dtype=torch.int32, device=dev), "n": len(ct),
+                  "dst": torch.tensor([self.views[i].data_ptr() for i in idx], dtype=torch.int64, device=dev),
+                  "up": PtrUploader(len(idx), dev)}
+            self._tabs[key] = tb
         src = tb["up"].upload([g.data_ptr() for g in grads])  # non-blocking: the host must not wait for the backward to drain
         lib().mt_copy(src.data_ptr(), tb["dst"].data_ptr(), tb["sizes"].data_ptr(), tb["ct"].data_ptr(), tb["co"].data_ptr(), tb["n"], self.CHUNK,
                       1.0, ops.stream())
 
-    def reduce(self):
-        """gather -> all-reduce(SUM) -> p.grad = slot views.  Call after backward, before the optimizer step."""
-        active = [i for i, p in enumerate(self.params) if p.grad is not None]
-        grads = []
-        for i in active:
+    def _launch(self, b):
+        a, e = self.buckets[b]
+        idx, grads = [], []
+        for i in range(a, e):
             g = self.params[i].grad
+            if g is None or g.data_ptr() == self.views[i].data_ptr():
+                continue  # no gradient (slot stays zero), or accumulated in place into the slot already
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.float().contiguous()
+            idx.append(i)
             grads.append(g)
-        self._gather(active, grads)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat)
-        for i in active:
-            self.params[i].grad = self.views[i]
+        lo = self.offs[a]
+        hi = self.offs[e - 1] + self.sizes[e - 1]
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        if self.comm is not None:
+            ev = torch.cuda.Event(enable_timing=self.timing)
+            ev.record()  # compute stream: everything that produced this bucket's gradients has been enqueued
+            self.comm.wait_event(ev)
+            with torch.cuda.stream(self.comm):
+                # the side stream is ONE timeline: gather(b), all-reduce(b), gather(b+1), ...  (with RCCL `wait()` only orders the
+                # stream behind the collective; host-staged backends block the host here, which a rehearsal tolerates)
+                if idx:
+                    self._gather(idx, grads)
+                t0 = t1 = None
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                if multi:
+                    dist.all_reduce(self.flat[lo:hi], async_op=True).wait()
+                if self.timing:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record()
+                    self._events.append((ev, t0, t1, hi - lo))
+            self._keep.append(grads)  # the sources stay alive until finish() has ordered the compute stream behind the copies
+        else:
+            if idx:
+                self._gather(idx, grads)
+            if multi:
+                self._works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+
+    def finish(self):
+        """Call after backward, before the optimizer step: launch the remaining buckets, wait for the collectives (the compute
+        stream waits, not the host), p.grad = slot views.  -> the flat buffer"""
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+            self._next += 1
+        for w in self._works:
+            w.wait()
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        for i, p in enumerate(self.params):
+            if p.grad is not None:
+                p.grad = self.views[i]
+        events = self._events
+        self._reset()
+        self._events_done = events if (self.timing and events) else None
         return self.flat
+
+    reduce = finish  # round-1 name
+
+    def times(self):
+        """timing=True: per-bucket (bytes, ms from 'gradients ready' to 'all-reduce done', all-reduce ms) of the last finished step
+        (call after a synchronize)"""
+        ev = getattr(self, "_events_done", None)
+        if not ev:
+            return None
+        return [(4 * n, e0.elapsed_time(t1), t0.elapsed_time(t1)) for e0, t0, t1, n in ev]
 
 
 def scale_loss(loss: torch.Tensor, world: int) -> torch.Tensor:

@@ -483,10 +483,10 @@ class v10Detect3d(nn.Module):
                 lo, hi = mid, 8 * mid
                 w1, g1, b1, rm1, rv1 = s1.tensors()
                 z1 = ops.conv_bn_act_eval(patches, w1[lo:hi], g1[lo:hi], b1[lo:hi], rm1[lo:hi], rv1[lo:hi], self.kernel_size_1, 1, 0, 1,
-                                          c0.has_act, c0.eps, s1.__dict__.setdefault("_eval_cache", {}))
+                                          c0.has_act, c0.eps, s1.__dict__.setdefault("_eval_cache", {}), ver=s1.ver)
                 w2, g2, b2, rm2, rv2 = s2.tensors()
                 z2 = ops.conv_bn_act_eval(z1, w2[lo:hi], g2[lo:hi], b2[lo:hi], rm2[lo:hi], rv2[lo:hi], self.kernel_size_2, 1, 0, 7,
-                                          c0.has_act, c0.eps, s2.__dict__.setdefault("_eval_cache", {}))
+                                          c0.has_act, c0.eps, s2.__dict__.setdefault("_eval_cache", {}), ver=s2.ver)
                 reg = ops.HeadProjSlicesFn.apply(z2, [j * mid for j in range(7)], [mid] * 7, 7, *[heads[j][i][2].weight for j in range(1, 8)],
                                                  *[heads[j][i][2].bias for j in range(1, 8)])[:, :, 0, 0]
             else:
@@ -532,26 +532,28 @@ class v10Detect3d(nn.Module):
             one2many, o2m_embs = self.forward_feat(x, self.o2m_heads)
         return {"one2many": one2many, "one2one": one2one, "o2m_embs": o2m_embs, "o2o_embs": o2o_embs, "depth_maps": torch.empty(1)}
 
+    # head.py:847-871 as data: per number of levels, the depth bias of each level and the uniform range of its depth projection
+    # weights; (bias fill, weight init) of the other branches.  The class prior assumes KITTI's 1280 x 384 images, as the reference does.
+    DEPTH_PRIOR = {1: ((40.0,), ((-3.5, 3.5),)), 2: ((45.0, 20.0), ((-2.0, 2.0), (-2.0, 2.0))),
+                   3: ((45.0, 25.0, 10.0), ((-2.0, 2.0), (-1.5, 1.5), (-1.0, 1.0)))}
+    BIAS_FILL = {"s2d": 6.0, "o2d": 0.0, "o3d": 0.0, "s3d": 0.0}
+    S3D_WEIGHT_STD = 0.05
+    PRIOR_IMAGE = (1280.0, 384.0)
+
     def bias_init(self):
-        """reference head.py:847-871 (KITTI 1280x384 prior hard-coded there)"""
-        if self.nl == 1:
-            deps, ranges = [40], [[-3.5, 3.5]]
-        elif self.nl == 2:
-            deps, ranges = [45, 20], [[-2, 2], [-2, 2]]
-        elif self.nl == 3:
-            deps, ranges = [45, 25, 10], [[-2, 2], [-1.5, 1.5], [-1, 1]]
-        else:
+        """reference head.py:847-871; pinned by tests/golden/bias_init.npz (tests/test_host_logic.py)"""
+        if self.nl not in self.DEPTH_PRIOR:
             raise RuntimeError("Initialization only set for 1 and 3 scales")
+        deps, ranges = self.DEPTH_PRIOR[self.nl]
         for i in range(self.nl):
             s = float(self.stride[i])
-            self.cls[i][-1].bias.data[: self.nc] = math.log(5 / self.nc / ((1280 / s) * (384 / s)))
-            self.s2d[i][-1].bias.data.fill_(6)
-            self.o2d[i][-1].bias.data.fill_(0)
-            self.o3d[i][-1].bias.data.fill_(0)
-            self.s3d[i][-1].bias.data.fill_(0.0)
-            nn.init.normal_(self.s3d[i][-1].weight, std=0.05)
+            self.cls[i][-1].bias.data[: self.nc] = math.log(5 / self.nc / ((self.PRIOR_IMAGE[0] / s) * (self.PRIOR_IMAGE[1] / s)))
+            for name, v in self.BIAS_FILL.items():
+                getattr(self, name)[i][-1].bias.data.fill_(v)
+            nn.init.normal_(self.s3d[i][-1].weight, std=self.S3D_WEIGHT_STD)
             self.dep[i][-1].bias.data.fill_(deps[i])
             nn.init.uniform_(self.dep[i][-1].weight, a=ranges[i][0], b=ranges[i][1])
+        # the one-to-one set aliases the named branches, the one-to-many set restarts as its copy (head.py:869-870)
         self.o2o_heads = nn.ModuleList([self.cls, self.o2d, self.s2d, self.o3d, self.s3d, self.hd, self.dep, self.dep_un])
         self.o2m_heads = copy.deepcopy(self.o2o_heads)
 

@@ -179,16 +179,20 @@ class _PackRegistry:
         _, desc, ct, co, n = self.tables
         lib().mt_pack_weights(dt, desc.data_ptr(), ct.data_ptr(), co.data_ptr(), n, self.CHUNK, stream())
 
-    def lookup(self, w32, src_ptr, geo, dtype):
-        """geo = (a, b, c, taps, Kpad, dt) as y3d_mt_pack_weights; src_ptr: address of the (sub)tensor to pack -> packed tensor"""
+    def lookup(self, w32, src_ptr, geo, dtype, ver=None):
+        """geo = (a, b, c, taps, Kpad, dt) as y3d_mt_pack_weights; src_ptr: address of the (sub)tensor to pack -> packed tensor.
+        `ver`: the torch-side version token of the weights (default: w32's own counter).  A stacked weight passes the counters of
+        its per-branch Parameters: they are re-pointed at slices of the flat tensor with `.data =`, which shares storage but NOT the
+        version counter, so torch-side writers (torch.optim, load_state_dict, init, broadcast) move only the Parameters' counters."""
         key = (src_ptr, geo)
+        ver = w32._version if ver is None else ver
         e = self.entries.get(key)
         now = (WEIGHT_EPOCH, geo[5])
         if e is None:
             a, b, c, taps, kpad, dt = geo
             n = a * kpad if self.mode == 0 else a * c * kpad
             # "keep": the registry re-reads `src` at every epoch, so the storage behind it must outlive the entry
-            e = {"src": src_ptr, "geo": geo, "dst": torch.empty(n, dtype=dtype, device=w32.device), "ver": w32._version, "seen": WEIGHT_EPOCH,
+            e = {"src": src_ptr, "geo": geo, "dst": torch.empty(n, dtype=dtype, device=w32.device), "ver": ver, "seen": WEIGHT_EPOCH,
                  "keep": w32}
             self.entries[key] = e
             self._pack_one(e)
@@ -204,9 +208,9 @@ class _PackRegistry:
                 if v["geo"][5] == geo[5]:
                     v["ver"] = None  # refreshed from memory: whatever version the tensor has now is the packed one
         if e["ver"] is None:
-            e["ver"] = w32._version
-        elif e["ver"] != w32._version:  # changed through torch since it was packed (load_state_dict, init, broadcast)
-            e["ver"] = w32._version
+            e["ver"] = ver
+        elif e["ver"] != ver:  # changed through torch since it was packed (load_state_dict, init, broadcast, torch.optim)
+            e["ver"] = ver
             self._pack_one(e)
         return e["dst"]
 
@@ -218,10 +222,11 @@ PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv pac
 # ------------------------------------------------------------------------------------------------------
 # Conv (dense / grouped / depth-wise) + BatchNorm + SiLU + residual
 # ------------------------------------------------------------------------------------------------------
-def conv_bn_act_eval(x, w, gamma, beta, rm, rv, k, s, p, g, act, eps, cache=None):
+def conv_bn_act_eval(x, w, gamma, beta, rm, rv, k, s, p, g, act, eps, cache=None, ver=None):
     """eval-mode act(bn(conv(x))) on explicit (possibly stacked / sliced) tensors; no autograd.  `cache`: a dict owned by the
-    caller that keeps the packed weights + folded BatchNorm scale/shift until a parameter changes"""
-    z, _, _ = _cba_forward(x, w, gamma, beta, rm, rv, k, s, p, g, act, None, 0, False, eps, 0.0, cache)
+    caller that keeps the packed weights + folded BatchNorm scale/shift until a parameter changes; `ver`: version token of the
+    tensors behind a stacked view (StackedConvs.ver)"""
+    z, _, _ = _cba_forward(x, w, gamma, beta, rm, rv, k, s, p, g, act, None, 0, False, eps, 0.0, cache, ver=ver)
     return z
 
 
@@ -232,8 +237,10 @@ def _timed(key, launch):
         launch()
 
 
-def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True, pack_cache=True):
-    """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs."""
+def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True, pack_cache=True,
+                 ver=None):
+    """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs.
+    ver = (weights token, all-tensors token) of a stacked view (StackedConvs), None for tensors that carry their own counters."""
     L = lib()
     _require_gpu(x)
     dtype = _COMPUTE_DTYPE
@@ -293,8 +300,8 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         if not training and not res_mode:
             # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor; the packed
             # weights and the scale/shift pair are cached until a parameter / buffer is modified in place or re-pointed
-            key = (PARAM_EPOCH, w32.data_ptr(), w32._version, g32.data_ptr(), g32._version, b32._version, rm.data_ptr(), rm._version, rv._version,
-                   dtype, k, g, Cg_pad, Cout, float(eps))
+            vkey = ver[1] if ver is not None else (w32._version, g32._version, b32._version, rm._version, rv._version)
+            key = (PARAM_EPOCH, w32.data_ptr(), g32.data_ptr(), rm.data_ptr(), vkey, dtype, k, g, Cg_pad, Cout, float(eps))
             hit = cache.get(key) if cache is not None else None
             if hit is None:
                 wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
@@ -310,7 +317,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                                 y.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p, st)
             return y, None, None
         if pack_cache and training and PACK_CACHE:
-            wp = PACK_FWD.lookup(w32, w32.data_ptr(), (Cout, Cin // g, Cg_pad, k * k, k * k * Cg_pad, dt), dtype)
+            wp = PACK_FWD.lookup(w32, w32.data_ptr(), (Cout, Cin // g, Cg_pad, k * k, k * k * Cg_pad, dt), dtype, ver[0] if ver is not None else None)
         else:
             wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
             L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
@@ -338,7 +345,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
 
 
-def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
+def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None, wver=None):
     """-> dx, dW (fp32 OIHW), dgamma, dbeta, dres.  dx_range=(lo, hi): only output channels lo..hi feed dx
     (the one-to-one head sees a detached input, reference head.py:820)."""
     L = lib()
@@ -348,7 +355,7 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
     if not training:
         raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
     if pre is not None:  # (dy, dgb): the BatchNorm part was done by the caller (FusedConvBNProjFn)
-        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range)
+        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range, wver)
     dt = code(dtype)
     st = stream()
     dev = dz.device
@@ -372,10 +379,10 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
                        dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
     if res_mode == 1:
         dres = dz
-    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range)
+    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, wver)
 
 
-def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
+def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, wver=None):
     """data and weight gradients of the conv given dy (gradient wrt its pre-BatchNorm output)"""
     L = lib()
     xin, w32, y, stats, rr = saved
@@ -410,7 +417,7 @@ def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
                 wpd = torch.empty(Cin * kp, dtype=dtype, device=dev)
                 L.pack_weight_dgrad(dt, src, wpd.data_ptr(), co, Cin // g, g, k, k, st)
             else:
-                wpd = PACK_DGRAD.lookup(w32, src, (g, co // g, Cin // g, k * k, kp, dt), dtype)
+                wpd = PACK_DGRAD.lookup(w32, src, (g, co // g, Cin // g, k * k, kp, dt), dtype, wver)
             dx = nhwc_empty(B, Cin, H, W, dtype, dev)
             dsb, dsh, dsw = s3(dy)
             _timed(("conv_dgrad", dt, B, H, W, Cin, co, k, s, g),
@@ -500,6 +507,10 @@ class StackedConvs:
         rm = self._ensure("rm", [c.bn.running_mean for c in cs], lambda i, v: cs[i].bn._buffers.__setitem__("running_mean", v))
         rv = self._ensure("rv", [c.bn.running_var for c in cs], lambda i, v: cs[i].bn._buffers.__setitem__("running_var", v))
         c0 = cs[0].conv
+        # identity of what the flat tensors hold, as torch sees it: the per-branch tensors' own version counters (the flat views'
+        # counters never move: `.data =` shares storage, not the counter)
+        wv = tuple(c.conv.weight._version for c in cs)
+        self.ver = (wv, wv + tuple(t._version for c in cs for t in (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var)))
         return w.view(sum(self.couts), c0.in_channels // c0.groups, *c0.kernel_size), gm, bt, rm, rv
 
     def params(self):
@@ -514,18 +525,18 @@ class FusedConvBNActFn(torch.autograd.Function):
     def forward(ctx, x, stack, groups, dx_range, *params):
         w, gm, bt, rm, rv = stack.tensors()
         m = stack.convs[0]
-        z, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum)
+        z, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum, ver=stack.ver)
         if m.training:
             for c in stack.convs:
                 c._nbt_pending += 1
-        ctx.cfg, ctx.couts, ctx.dx_range = cfg, stack.couts, dx_range
+        ctx.cfg, ctx.couts, ctx.dx_range, ctx.wver = cfg, stack.couts, dx_range, stack.ver[0]
         if saved is not None:
             ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range)
+        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range, wver=ctx.wver)
         dWs, dgs, dbs, off = [], [], [], 0
         for co in ctx.couts:
             dWs.append(dW[off:off + co])
@@ -763,7 +774,9 @@ class FusedConvBNProjFn(torch.autograd.Function):
         m = stack.convs[0]
         npar = len(params) - 2 * n
         ws, bs = params[npar:npar + n], params[npar + n:]
-        y, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum, bn_apply=False)
+        y, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum, bn_apply=False,
+                                     ver=stack.ver)
+        ctx.wver = stack.ver[0]
         if m.training:
             for c in stack.convs:
                 c._nbt_pending += 1
@@ -815,7 +828,7 @@ class FusedConvBNProjFn(torch.autograd.Function):
         L.proj_group_bwd_weight_bn(dt, n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, stats[2].data_ptr(),
                                    stats[3].data_ptr(), act, slab.data_ptr(), bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]),
                                    PV(*[t.data_ptr() for t in dbs]), P, st)
-        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None)
+        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None, wver=ctx.wver)
         dWs, dgs, dbs_s, off = [], [], [], 0
         for co in ctx.couts_stack:
             dWs.append(dW[off:off + co])
