@@ -277,7 +277,9 @@ def test_stacked_head_under_torch_optim_matches_fused_sgd():
         oa.zero_grad(set_to_none=True)
         ob.zero_grad(set_to_none=True)
     for (k, p), q in zip(ma.named_parameters(), mb.parameters()):
-        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), f"{k} differs after 3 steps: {(p - q).abs().max():.3e}"
+        # unclipped steps on a loss of O(1000): per-tensor max-norm (a stale stacked weight shows as O(1) relative differences)
+        e = float((p.detach() - q.detach()).abs().max() / p.detach().abs().max().clamp(min=1e-3))
+        assert e <= 1e-3, f"{k} differs after 3 steps: {e:.3e} relative"
 
 
 def test_assignment_does_not_depend_on_padded_row_bound():
