@@ -12,7 +12,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o run --
 echo stats done
 python3 $R/tools/prof_summary.py $O/${TAG}_prof 5 60 > $O/${TAG}_bench_kernel_stats_summary.txt
 cp $(find $O/${TAG}_prof -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
-find $O/${TAG}_prof -name "*kernel_trace.csv" -delete   # tens of MB: summarised above
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_f -o run -- python3 $R/bench.py --steps 2 --warmup 1 --infer-steps 0 --no-cpu-baseline > $O/${TAG}_pmc_f.log 2>&1
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_w -o run -- python3 $R/bench.py --steps 2 --warmup 1 --infer-steps 0 --no-cpu-baseline > $O/${TAG}_pmc_w.log 2>&1

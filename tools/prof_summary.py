@@ -45,6 +45,13 @@ def main():
             grid = int(col(r, "Grid_Size_X", "Grid_Size")) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
             disp.append((t0, name, grid, t1 - t0))
     disp.sort()
+    # steady-state window: a kernel that runs exactly once per step (the fused SGD update) delimits the steps; everything before its
+    # first dispatch (model upload, EMA deep copy, first-step packing: thousands of one-time copies) is dropped, so are partial steps
+    marker = [i for i, x in enumerate(disp) if "mt_sgd_kernel" in x[1] or "mt_adamw_kernel" in x[1]]
+    if len(marker) >= 2:
+        disp = disp[marker[0] + 1: marker[-1] + 1]
+        steps = float(len(marker) - 1)
+        print(f"# steady-state window: {len(marker) - 1} steps between optimizer updates (set-up and the first step are excluded)")
     tot = sum(x[3] for x in disp)
     print(f"# {len(disp)} dispatches, total {tot / 1e6:.1f} ms  ({tot / 1e6 / steps:.2f} ms/step over {steps:g} steps)")
     by_name = defaultdict(lambda: [0, 0])

@@ -321,15 +321,24 @@ int launch_tile_epi(const C3P& p, hipStream_t st) {
 int y3d_conv3x3_wide_launch(int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w,
                             int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream);
 
+static int v2_max_tiles() {
+  static int v2max = -1;
+  if (v2max < 0) { const char* e = getenv("Y3D_V2_MAX_TILES"); v2max = e ? atoi(e) : 129; }
+  return v2max;
+}
+
 // tile height the resident-halo kernels would use for this geometry, 0 if the generic implicit GEMM must be used
-int y3d_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad) {
+int y3d_tile_height(int dtype, int B, int H, int W, int Cg, int Cn, int G, int kh, int kw, int stride, int pad) {
   int cse = 32;  // channels per K slab: 32 bf16 (64-byte rows, wide kernel) or 32 fp32 (128-byte rows)
   if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return 0;
   if (Cg % cse != 0 || Cg < 64 || Cn % 16 != 0) return 0;
   if (W < 8) return 0;
   if (H % 16 == 0) return 16;
   if (H % 8 == 0) return 8;
-  // smaller tiles (two waves per workgroup) measured slower than the generic implicit GEMM on 20x20 maps
+  // ragged height (20x20: the stride-32 level of a 640x640 image): the persistent bf16 kernel runs ceil(H / 8) row tiles and masks the
+  // rows past the map in its epilogue (20 rows in 24: 83 % useful MFMAs, against 440-650 TFLOP/s for the generic kernel on the P5
+  // head layers) - when there are enough tiles to fill the chip; the 256-pixel tile kernel (smaller shapes) needs H % TH == 0
+  if (dtype == Y3D_BF16 && H > 8 && (H % 8) >= 4 && (long)G * cdiv(B, 4) * cdiv(H, 8) * cdiv(W, 16) * cdiv(Cn, 128) >= v2_max_tiles()) return 8;
   return 0;
 }
 
@@ -340,15 +349,13 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
   p.x = x; p.w = w; p.y = y; p.part = part; p.scale = scale; p.shift = shift; p.act = act;
   p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = ysw;
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
-  p.ntx = cdiv(W, 16); p.nty = H / th; p.ntc = cdiv(Cn, 128); p.flip = flip;
+  p.ntx = cdiv(W, 16); p.nty = cdiv(H, th); p.ntc = cdiv(Cn, 128); p.flip = flip;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == Y3D_BF16) {
     // the persistent kernel runs one 512-pixel tile per CU at a time: with fewer tiles than half the CUs (128 -> 128 @40x40, B = 32:
     // 120) the 256-pixel tiles of this file's kernel fill the chip better (628 / 671 against 448 / 482 TFLOP/s forward / dgrad)
-    static int v2max = -1;
-    if (v2max < 0) { const char* e = getenv("Y3D_V2_MAX_TILES"); v2max = e ? atoi(e) : 129; }
     const long wide_tiles = (long)G * cdiv(B, 32 / th) * p.nty * p.ntx * p.ntc;
-    if (wide_tiles < v2max && Cg % 64 == 0)  // this kernel's K slab is a 128-byte row: 64 bf16 channels
+    if (wide_tiles < v2_max_tiles() && Cg % 64 == 0 && H % th == 0)  // this kernel's K slab is a 128-byte row: 64 bf16 channels
       return th == 16 ? launch_tile_epi<bf16_t, 16>(p, st) : launch_tile_epi<bf16_t, 8>(p, st);
     return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
   }

@@ -273,7 +273,10 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     for (int ct = 0; ct < 4; ++ct) fa[ct] = load_a1(gs & 3, ct);
     // store instructions of `cur`'s epilogue with at least one active lane: 8 per valid 32-channel pass (Cn % 64 may be 16 or 32; the
     // compiler branches around a store whose EXEC is empty).  Counting only those is the safe side for the wait below.
-    const int st_wave = cur.b0 + wimg < p.B ? (cur.c0 + wc * 64 + 32 < p.Cn ? NST : cur.c0 + wc * 64 < p.Cn ? NST / 2 : 0) : 0;
+    // Rows past a ragged map issue no store either: a LOWER bound of the issued stores, rounded down to the two counts the wait knows.
+    const int nvr = min(8, max(0, p.H - (cur.y0 + wrow0)));
+    const int st_issued = cur.b0 + wimg < p.B ? (cur.c0 + wc * 64 + 32 < p.Cn ? 2 * nvr : cur.c0 + wc * 64 < p.Cn ? nvr : 0) : 0;
+    const int st_wave = st_issued >= NST ? NST : (st_issued >= NST / 2 ? NST / 2 : 0);
 
 #pragma unroll 1
     for (int k = 0; k < nslab; ++k, ++gs) {
@@ -398,6 +401,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
       const int yy = cur.y0 + wrow0 + pt;
+      const bool pok = xok & (yy < p.H);  // rows past a ragged map (H % TH != 0) are computed and dropped
       bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + e_lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -408,14 +412,14 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
           for (int j = 0; j < 4; ++j) {
             float u = acc[2 * h + c2][pt][j];
             if (EPI == 1) { u = u * sv[h][c2 * 4 + j] + hv[h][c2 * 4 + j]; if (p.act) u = silu_f(u); }
-            u = xok ? bf2f(f2bf(u)) : 0.f;
+            u = pok ? bf2f(f2bf(u)) : 0.f;
             v[c2 * 4 + j] = u;
             if (EPI == 0) { ssum[h][c2 * 4 + j] += u; ssq[h][c2 * 4 + j] += u * u; }
           }
 #ifdef Y3D_PROBE_NOEPI
-        if (xok && cok[h] && v[0] == 123.456f) {
+        if (pok && cok[h] && v[0] == 123.456f) {
 #else
-        if (xok && cok[h]) {
+        if (pok && cok[h]) {
 #endif
           *(uint4*)(dst + h * 32) = Chunk<bf16_t>::pack(v);
         }
@@ -506,7 +510,7 @@ int launch_wide(const W3P& p, hipStream_t st) {
 
 }  // namespace
 
-int y3d_conv3x3_wide_ok(int H, int W, int Cg, int Cn) { return (H % 8 == 0) && W >= 8 && Cg % 32 == 0 && Cg >= 64 && Cn % 16 == 0; }
+int y3d_conv3x3_wide_ok(int H, int W, int Cg, int Cn) { return H >= 8 && W >= 8 && Cg % 32 == 0 && Cg >= 64 && Cn % 16 == 0; }
 
 int y3d_conv3x3_wide_launch(int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w,
                             int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream) {
@@ -514,7 +518,7 @@ int y3d_conv3x3_wide_launch(int th, const void* x, long xsb, long xsh, long xsw,
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.part = part; p.scale = scale; p.shift = shift; p.act = act;
   p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = ysw;
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
-  p.ntx = cdiv(W, 16); p.nty = H / th; p.ntc = cdiv(Cn, 128); p.nbt = cdiv(B, 32 / th); p.flip = flip;
+  p.ntx = cdiv(W, 16); p.nty = cdiv(H, th); p.ntc = cdiv(Cn, 128); p.nbt = cdiv(B, 32 / th); p.flip = flip;
   // extents in bytes (last addressable element + 1) of the input view and the packed weights; both must stay below 4 GB - 16
   const unsigned long xb = ((unsigned long)(B - 1) * xsb + (unsigned long)(H - 1) * xsh + (unsigned long)(W - 1) * xsw + (unsigned long)G * Cg) * 2;
   const unsigned long wb = (unsigned long)G * Cn * Ktot * 2;

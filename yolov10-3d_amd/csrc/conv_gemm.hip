@@ -643,7 +643,7 @@ int launch_conv(ConvP p, hipStream_t st) {
 }  // namespace
 
 // conv3x3_tile.hip
-int y3d_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad);
+int y3d_tile_height(int dtype, int B, int H, int W, int Cg, int Cn, int G, int kh, int kw, int stride, int pad);
 int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G,
                             const void* w, int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act,
                             void* stream);
@@ -677,8 +677,8 @@ int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int
 }
 
 int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
-  int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, H, W, Cin / groups, Cout / groups, kh, kw, stride, pad) : 0;
-  if (th) return B * (H / th) * cdiv(W, 16);
+  int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, B, H, W, Cin / groups, Cout / groups, groups, kh, kw, stride, pad) : 0;
+  if (th) return B * cdiv(H, th) * cdiv(W, 16);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   return cdiv((long)B * Ho * Wo, 128);
 }
@@ -745,7 +745,7 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
   if (!bias && g_tile_kernels) {
-    int th = y3d_tile_height(dtype, H, W, p.Cg, p.Cn, kh, kw, stride, pad);
+    int th = y3d_tile_height(dtype, B, H, W, p.Cg, p.Cn, groups, kh, kw, stride, pad);
     if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, scale, shift, act, stream);
   }
   if (dtype == Y3D_BF16) return launch_conv<bf16_t, false>(p, (hipStream_t)stream);
@@ -787,7 +787,7 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   p.Ktot = kh * kw * p.Cg; p.Kpad = y3d_conv_kpad(dtype, p.Ktot); p.M = B * H * W;
   if (g_tile_kernels) {
     // a 3x3 s1 p1 data gradient is the same conv on dy with flipped taps (Ho == H, Wo == W)
-    int th = y3d_tile_height(dtype, Ho, Wo, p.Cg, p.Cn, kh, kw, stride, pad);
+    int th = y3d_tile_height(dtype, B, Ho, Wo, p.Cg, p.Cn, groups, kh, kw, stride, pad);
     if (th && Ho == H && Wo == W)
       return y3d_conv3x3_tile_launch(dtype, th, dy, dsb, dsh, dsw, B, H, W, p.Cg, p.Cn, groups, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, nullptr, nullptr, 0, stream);
   }

@@ -43,6 +43,38 @@ def _flatten_maps(feats):
     return torch.cat([f.permute(0, 2, 3, 1).reshape(B, -1, no) for f in feats], 1).float()
 
 
+def _loss3d_set(cfg, gt, n_used, calib, mean_sizes, map_ptrs, psw, grad_ptrs, gsw, Hs, Ws, B, dtype, dev):
+    """one head set on the HIP kernels: assignment + six loss items + gradient rows written at grad_ptrs (pixel stride gsw).
+    -> (items[6], fg (B, A) uint8, gt_idx (B, A) int32, target_scores (B, A, nc))"""
+    L = lib()
+    strides, nc, topk, alpha, beta, gamma, w = cfg
+    dt, st, nl = ops.code(dtype), ops.stream(), len(map_ptrs)
+    A = sum(h * w_ for h, w_ in zip(Hs, Ws))
+    n = gt.shape[1]
+    PV = ctypes.c_void_p * nl
+    c_maps, c_grads = PV(*map_ptrs), PV(*grad_ptrs)
+    c_psw, c_gsw = (ctypes.c_int64 * nl)(*psw), (ctypes.c_int64 * nl)(*gsw)
+    c_H, c_W = (ctypes.c_int * nl)(*Hs), (ctypes.c_int * nl)(*Ws)
+    c_st = (ctypes.c_float * nl)(*strides)
+    nsc = L.tal3d_scratch_floats(B, n, A, topk)
+    if nsc < 0:
+        raise Y3DError("Loss3dFn: assignment scratch exceeds 2^31 floats")
+    scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
+    fg = torch.empty(B, A, dtype=torch.uint8, device=dev)
+    gi = torch.empty(B, A, dtype=torch.int32, device=dev)
+    ts = torch.empty(B, A, nc, dtype=torch.float32, device=dev)
+    scal = torch.empty(2, dtype=torch.float32, device=dev)
+    L.tal3d_assign(dt, nl, c_maps, c_psw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, calib.data_ptr(), mean_sizes.data_ptr(), topk,
+                   alpha, beta, gamma, scratch.data_ptr(), fg.data_ptr(), gi.data_ptr(), ts.data_ptr(), scal.data_ptr(),
+                   n_used.data_ptr() if n_used is not None else None, st)
+    nblk = (B * A + 255) // 256
+    part = torch.empty(nblk * 6, dtype=torch.float32, device=dev)
+    items = torch.empty(6, dtype=torch.float32, device=dev)
+    L.loss3d(dt, nl, c_maps, c_psw, c_grads, c_gsw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, fg.data_ptr(), gi.data_ptr(), ts.data_ptr(),
+             scal.data_ptr(), w[0], w[1], w[2], w[3], w[4], w[5], 1.0, part.data_ptr(), items.data_ptr(), st)
+    return items, fg, gi, ts
+
+
 class Loss3dFn(torch.autograd.Function):
     """One head set: task-aligned assignment (no grad) + the six 3D loss terms + d(sum of terms)/d(head maps), on the fused HIP
     kernels.  apply(cfg, gt(B,n,17), n_used, calib, mean_sizes, *maps) -> (sum_of_items, items[6], fg_mask, target_gt_idx, target_scores);
@@ -50,49 +82,18 @@ class Loss3dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, gt, n_used, calib, mean_sizes, *maps):
-        L = lib()
-        strides, nc, topk, alpha, beta, gamma, w = cfg
-        dtype = maps[0].dtype
-        dt = ops.code(dtype)
-        st = ops.stream()
-        dev = maps[0].device
-        nl = len(maps)
+        dtype, dev = maps[0].dtype, maps[0].device
         for m in maps:
             if not (m.is_cuda and ops.px_dense(m)):
                 raise Y3DError("Loss3dFn: head maps must be pixel-dense NHWC tensors on a HIP device")
         B, no = maps[0].shape[:2]
-        Hs = [m.shape[2] for m in maps]
-        Ws = [m.shape[3] for m in maps]
-        A = sum(h * w_ for h, w_ in zip(Hs, Ws))
-        n = gt.shape[1]
-        gt = gt.float().contiguous()
-        calib = calib.float().contiguous()
-        mean_sizes = mean_sizes.float().contiguous()
+        Hs, Ws = [m.shape[2] for m in maps], [m.shape[3] for m in maps]
         grads = [ops.nhwc_empty(B, no, h, w_, dtype, dev) for h, w_ in zip(Hs, Ws)]
-        PV = ctypes.c_void_p * nl
-        c_maps = PV(*[m.data_ptr() for m in maps])
-        c_grads = PV(*[g.data_ptr() for g in grads])
-        c_psw = (ctypes.c_int64 * nl)(*[m.stride(3) for m in maps])
-        c_gsw = (ctypes.c_int64 * nl)(*[no] * nl)
-        c_H, c_W = (ctypes.c_int * nl)(*Hs), (ctypes.c_int * nl)(*Ws)
-        c_st = (ctypes.c_float * nl)(*strides)
-        nsc = L.tal3d_scratch_floats(B, n, A, topk)
-        if nsc < 0:
-            raise Y3DError("Loss3dFn: assignment scratch exceeds 2^31 floats")
-        scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
-        fg = torch.empty(B, A, dtype=torch.uint8, device=dev)
-        gi = torch.empty(B, A, dtype=torch.int32, device=dev)
-        ts = torch.empty(B, A, nc, dtype=torch.float32, device=dev)
-        scal = torch.empty(2, dtype=torch.float32, device=dev)
-        L.tal3d_assign(dt, nl, c_maps, c_psw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, calib.data_ptr(), mean_sizes.data_ptr(), topk,
-                       alpha, beta, gamma, scratch.data_ptr(), fg.data_ptr(), gi.data_ptr(), ts.data_ptr(), scal.data_ptr(),
-                       n_used.data_ptr() if n_used is not None else None, st)
-        nblk = (B * A + 255) // 256
-        part = torch.empty(nblk * 6, dtype=torch.float32, device=dev)
-        items = torch.empty(6, dtype=torch.float32, device=dev)
-        L.loss3d(dt, nl, c_maps, c_psw, c_grads, c_gsw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, fg.data_ptr(), gi.data_ptr(), ts.data_ptr(),
-                 scal.data_ptr(), w[0], w[1], w[2], w[3], w[4], w[5], 1.0, part.data_ptr(), items.data_ptr(), st)
+        items, fg, gi, ts = _loss3d_set(cfg, gt.float().contiguous(), n_used, calib.float().contiguous(), mean_sizes.float().contiguous(),
+                                        [m.data_ptr() for m in maps], [m.stride(3) for m in maps], [g.data_ptr() for g in grads],
+                                        [no] * len(maps), Hs, Ws, B, dtype, dev)
         ctx.save_for_backward(*grads)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the assignment outputs
         total = items.sum()
         ctx.mark_non_differentiable(items, fg, gi, ts)
         return total, items, fg, gi, ts
@@ -100,7 +101,50 @@ class Loss3dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_total, *unused):
         grads = ctx.saved_tensors
+        if d_total is None:
+            return (None,) * (5 + len(grads))
         return (None, None, None, None, None, *[g * d_total.to(g.dtype) for g in grads])
+
+
+class DualLoss3dFn(torch.autograd.Function):
+    """Both head sets of a step on the head's own (B, 2*no, H, W) maps ([one-to-one | one-to-many] channels, as
+    v10Detect3d.forward_train_fused writes them): the gradient rows of both sets go into ONE NHWC tensor per level and the backward
+    is one broadcast multiply per level.  With the two sets as separate autograd inputs (channel slices of that map) autograd
+    zero-fills a full map per slice, copies, adds and re-lays the sum out: 7 elementwise launches per level instead of 1.
+    apply(cfg_o2o, cfg_o2m, gt, n_used, calib, mean_sizes, *maps) -> (total_o2o, items_o2o, total_o2m, items_o2m, fg1, gi1, ts1, fgm, gim, tsm)"""
+
+    @staticmethod
+    def forward(ctx, cfg1, cfgm, gt, n_used, calib, mean_sizes, *maps):
+        dtype, dev = maps[0].dtype, maps[0].device
+        for m in maps:
+            if not (m.is_cuda and ops.px_dense(m)):
+                raise Y3DError("DualLoss3dFn: head maps must be pixel-dense NHWC tensors on a HIP device")
+        B, no2 = maps[0].shape[:2]
+        no, esz = no2 // 2, maps[0].element_size()
+        Hs, Ws = [m.shape[2] for m in maps], [m.shape[3] for m in maps]
+        grads = [ops.nhwc_empty(B, no2, h, w_, dtype, dev) for h, w_ in zip(Hs, Ws)]
+        gt, calib, mean_sizes = gt.float().contiguous(), calib.float().contiguous(), mean_sizes.float().contiguous()
+        outs = []
+        for cfg, off in ((cfg1, 0), (cfgm, no)):
+            outs.append(_loss3d_set(cfg, gt, n_used, calib, mean_sizes, [m.data_ptr() + off * esz for m in maps], [m.stride(3) for m in maps],
+                                    [g.data_ptr() + off * esz for g in grads], [no2] * len(maps), Hs, Ws, B, dtype, dev))
+        ctx.save_for_backward(*grads)
+        ctx.no = no
+        ctx.set_materialize_grads(False)
+        (i1, fg1, gi1, ts1), (im, fgm, gim, tsm) = outs
+        ctx.mark_non_differentiable(i1, im, fg1, gi1, ts1, fgm, gim, tsm)
+        return i1.sum(), i1, im.sum(), im, fg1, gi1, ts1, fgm, gim, tsm
+
+    @staticmethod
+    def backward(ctx, d1, _i1, dm, *unused):
+        grads = ctx.saved_tensors
+        if d1 is None and dm is None:
+            return (None,) * (6 + len(grads))
+        no = ctx.no
+        z = torch.zeros((), dtype=torch.float32, device=grads[0].device)
+        scale = torch.cat(((d1 if d1 is not None else z).float().reshape(1).expand(no), (dm if dm is not None else z).float().reshape(1).expand(no)))
+        scale = scale.to(grads[0].dtype).view(1, 2 * no, 1, 1)
+        return (None, None, None, None, None, None, *[g * scale for g in grads])
 
 
 class DDDetectionLoss:
@@ -141,13 +185,21 @@ class DDDetectionLoss:
             loss = torch.zeros(6, device=dev)
             return loss.sum() * B, loss  # reference: graph-less zeros (loss.py:873-877); callers skip the step
         g, n_used = targets
-        h = self.hyp
-        cfg = (self.stride[: len(feats)], self.nc, self.topk, float(h.tal_alpha), float(h.tal_beta), float(h.tal_gamma),
-               (float(h.loss2d), float(h.cls), float(h.depth), float(h.offset3d), float(h.size3d), float(h.heading)))
         maps = [f if f.dtype == ops.compute_dtype() else f.to(ops.compute_dtype()) for f in feats]
-        total, items, fg, gt_idx, t_sc = Loss3dFn.apply(cfg, g, n_used, batch["calib"].to(dev), batch["mean_sizes"].to(dev), *maps)
-        self.last_assignment = (fg.bool(), gt_idx.long(), t_sc)
+        total, items, fg, gt_idx, t_sc = Loss3dFn.apply(self.cfg(len(feats)), g, n_used, batch["calib"].to(dev), batch["mean_sizes"].to(dev), *maps)
+        self._assignment = (fg, gt_idx, t_sc)
         return total * B, items
+
+    def cfg(self, nl):
+        h = self.hyp
+        return (self.stride[:nl], self.nc, self.topk, float(h.tal_alpha), float(h.tal_beta), float(h.tal_gamma),
+                (float(h.loss2d), float(h.cls), float(h.depth), float(h.offset3d), float(h.size3d), float(h.heading)))
+
+    @property
+    def last_assignment(self):
+        """(fg_mask bool, target_gt_idx int64, target_scores) of the last call, in the reference's dtypes (converted on access)"""
+        fg, gi, ts = self._assignment
+        return fg.bool(), gi.long(), ts
 
 
 class DetectLoss3d:
@@ -157,14 +209,38 @@ class DetectLoss3d:
         self.one2many = DDDetectionLoss(model, tal_topk=model.args.tal_topk)
         self.one2one = DDDetectionLoss(model, tal_topk=1)
 
+    @staticmethod
+    def _shared_maps(maps, o2o, o2m, no):
+        """`maps`: the head's own (B, 2*no, H, W) tensors (preds["_y3d_maps"], written by v10Detect3d.forward_train_fused), accepted
+        only when the two head sets really are their channel halves [one-to-one | one-to-many]; else None"""
+        if not maps or len(maps) != len(o2o) or len(o2o) != len(o2m):
+            return None
+        for base, a, b in zip(maps, o2o, o2m):
+            if (base.dim() != 4 or base.shape[1] != 2 * no or a.shape[1] != no or b.shape[1] != no or base.dtype != ops.compute_dtype()
+                    or not ops.px_dense(base) or a.stride() != base.stride() or b.stride() != base.stride()
+                    or a.data_ptr() != base.data_ptr() or b.data_ptr() != base.data_ptr() + no * base.element_size()):
+                return None
+        return list(maps)
+
     def __call__(self, preds, batch):
-        f0 = preds["one2one"][1] if isinstance(preds["one2one"], tuple) else preds["one2one"]
-        tg = self.one2one.targets(batch, f0[0].shape[0], f0[0].shape[2], f0[0].shape[3], f0[0].device)  # padded once per step
-        if tg is None:
-            tg = ()
-        kw = {"targets": tg} if tg else {}
+        o2o = preds["one2one"][1] if isinstance(preds["one2one"], tuple) else preds["one2one"]
+        dev = o2o[0].device
+        B, (H, W) = o2o[0].shape[0], o2o[0].shape[2:]
+        tg = self.one2one.targets(batch, B, H, W, dev) if o2o[0].is_cuda else None  # padded once per step
+        kw = {"targets": tg} if tg is not None else {}
+        o2m = preds.get("one2many", None)
+        if o2m and tg is not None:
+            o2m = o2m[1] if isinstance(o2m, tuple) else o2m
+            bases = self._shared_maps(preds.get("_y3d_maps"), o2o, o2m, self.one2one.no)
+            if bases is not None:
+                g, n_used = tg
+                nl = len(bases)
+                t1, i1, tm, im, fg1, gi1, ts1, fgm, gim, tsm = DualLoss3dFn.apply(self.one2one.cfg(nl), self.one2many.cfg(nl), g, n_used, batch["calib"].to(dev),
+                                                                                  batch["mean_sizes"].to(dev), *bases)
+                self.one2one._assignment, self.one2many._assignment = (fg1, gi1, ts1), (fgm, gim, tsm)
+                return tm * B + t1 * B, torch.cat((im, i1))
         l1, i1 = self.one2one(preds["one2one"], batch, embeddings=preds.get("o2o_embs"), **kw)
-        if preds.get("one2many", None):
+        if o2m:
             lm, im = self.one2many(preds["one2many"], batch, embeddings=preds.get("o2m_embs"), **kw)
             return lm + l1, torch.cat((im, i1))
         return torch.zeros(1), i1
@@ -215,12 +291,15 @@ class Loss2dFn(torch.autograd.Function):
         L.loss2d(dt, nl, c_maps, c_psw, c_grads, c_gsw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, fg.data_ptr(), gi.data_ptr(), ts.data_ptr(),
                  scal.data_ptr(), w[0], w[1], w[2], 1.0, part.data_ptr(), items.data_ptr(), st)
         ctx.save_for_backward(*grads)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the assignment outputs
         total = items.sum()
         ctx.mark_non_differentiable(items, fg, gi, ts)
         return total, items, fg, gi, ts
 
     @staticmethod
     def backward(ctx, d_total, *unused):
+        if d_total is None:
+            return (None,) * (3 + len(ctx.saved_tensors))
         return (None, None, None, *[g * d_total.to(g.dtype) for g in ctx.saved_tensors])
 
 

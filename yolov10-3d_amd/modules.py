@@ -415,6 +415,7 @@ class v10Detect3d(nn.Module):
         it sees x.detach(), head.py:820), ONE grouped conv (16 groups of mid -> mid), ONE projection launch set writing the
         (B, 2*no, H, W) map.  Numerically identical to the per-branch form (BatchNorm is per channel)."""
         o2o, o2m, e_o2o, e_o2m = [], [], [], []
+        self._maps = []  # the (B, 2*no, H, W) maps the two head sets are channel halves of: the fused loss takes them whole
         for i in range(self.nl):
             branches, mids, s1, s2, parts, pos = self._stacks(i)
             half = sum(mids[:8])
@@ -443,6 +444,7 @@ class v10Detect3d(nn.Module):
             else:
                 feats = [b[1](zj) for b, zj in zip(branches, ops.SplitChannelsFn.apply(z1, offs, mids))]
                 out = _proj([b[2] for b in branches], feats)
+            self._maps.append(out)
             o2o.append(out[:, : self.no])
             o2m.append(out[:, self.no:])
             e_o2o.append(z1[:, offs[pos[6]]:offs[pos[6]] + mids[pos[6]]])
@@ -530,7 +532,10 @@ class v10Detect3d(nn.Module):
         else:
             one2one, o2o_embs = self.forward_feat([xi.detach() for xi in x], self.o2o_heads)
             one2many, o2m_embs = self.forward_feat(x, self.o2m_heads)
-        return {"one2many": one2many, "one2one": one2one, "o2m_embs": o2m_embs, "o2o_embs": o2o_embs, "depth_maps": torch.empty(1)}
+        out = {"one2many": one2many, "one2one": one2one, "o2m_embs": o2m_embs, "o2o_embs": o2o_embs, "depth_maps": torch.empty(1)}
+        if self.fused:
+            out["_y3d_maps"] = self.__dict__.pop("_maps")  # private extra next to the reference's keys (head.py:833)
+        return out
 
     # head.py:847-871 as data: per number of levels, the depth bias of each level and the uniform range of its depth projection
     # weights; (bias fill, weight init) of the other branches.  The class prior assumes KITTI's 1280 x 384 images, as the reference does.
