@@ -249,12 +249,33 @@ int y3d_head3d_scatter(int dtype, const void* cls, int64_t csw, const void* reg,
 /* y (B, nc+35, A) fp32 from the per-level (B, H, W, nc+35) maps: xyxy px boxes, centre-3d px, the rest copied */
 int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, const int* W, const float* strides, int B, int nc,
                       float* y, void* stream);
+/* 2D head decode — Detect.inference head.py:53-79 (DFL softmax expectation block.py:59-62, dist2bbox(xywh) tal.py:315-325, sigmoid):
+ * maps[l] (B, H, W, 64 + nc) NHWC pixel-dense with channels [4 x 16 box-side bins | nc class logits] -> y (B, 4 + nc, A) fp32 =
+ * (cx, cy, w, h) px | scores */
+int y3d_head2d_decode(int dtype, int nl, const void* const* maps, const int* H, const int* W, const float* strides, int B, int nc,
+                      float* y, void* stream);
 /* y (B, C, A) fp32; scores are the first nc rows (3D, boxes_first = 0) or the last nc rows (2D, boxes_first = 1).
  * reg (B, max_det, C-nc), scores (B, max_det), labels (B, max_det) int64 */
 int y3d_v10_postprocess_scratch_floats(int B, int A, int nc, int max_det); /* 0 when the score row fits LDS, else B*A */
 int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
                         int64_t* labels, float* scratch, void* stream);
 
+/* Input pipeline, image side of KITTIDataset.__getitem__ (data/datasets/kitti.py:132-206): mirror (:149, :184), mixup blend
+ * `Image.blend(img, img2, 0.5)` (:188), affine crop `img.transform(resolution, AFFINE, trans_inv, BILINEAR)` (:192-196) in
+ * Pillow's arithmetic (bit-exact: double-precision mapping of pixel centres, clamped bilinear taps, truncation), `/255` (:204).
+ * src / src2: DEVICE arrays of B device pointers to (H, W, 3) uint8 RGB images (src2 entries or src2 itself may be NULL: no mixup);
+ * hw (B, 2) int32 source sizes, flip (B) int32, trans_inv (B, 6) float64 (output -> source), all on the device.
+ * mode 0: out (B, 3, out_h, out_w) fp32 = the reference's tensor; mode 1: out (B, out_h, out_w, 3) uint8 (feeds y3d_stem_im2col_u8,
+ * which divides by 255 itself). */
+int y3d_kitti_image_aug(const unsigned char* const* src, const unsigned char* const* src2, const int* hw, const int* flip, const double* trans_inv,
+                        int B, int out_h, int out_w, int mode, void* out, void* stream);
+/* One-to-many depth fusion of the 3D validator — YOLOv10_3DDetectionValidator.aggregate_o2m_preds models/yolov10_3D/val.py:78-102:
+ * predsO (B, K, C), predsM (B, KM, C) post-processed rows [xyxy | ... | depth (C-4) | depth log-variance (C-3) | score | label (C-1)];
+ * the one-to-many rows with IoU > iou_thres, the same label and exp(-log-variance) > thres vote on the depth through a weighted
+ * gaussian kernel density (silverman bandwidth as scikit-learn defines it), evaluated at nprop float32 proposals between the
+ * extreme votes; out (B, K, C) = predsO with the most likely proposal as depth. */
+int y3d_kde_depth_fusion(const float* predsO, int B, int K, const float* predsM, int KM, int C, float thres, float iou_thres, int nprop,
+                         float* out, void* stream);
 /* KITTI decode of the post-processed detections (data/datasets/kitti.py:519-576 `decode_preds`, called by the validator's
  * `_prepare_preds`, models/yolov10_3D/val.py:210-214).  preds (B, K, 37) fp32 rows [xyxy | centre-3d | size residual | 24 heading |
  * depth | depth log-variance | score logit | label]; calib (B, 6) = (cu, cv, fu, fv, tx, ty) of the original image; ratio (B, 2) =

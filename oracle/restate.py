@@ -918,3 +918,115 @@ def kitti_decode(preds, calib, ratio, inv_trans, mean_size=KITTI_MEAN_SIZE, thre
             out[i, j] = [cid, alpha, *box, *dim.astype(np.float64), lx, ly, lz, ry, score]
             keep[i, j] = not (score < threshold)
     return out, keep
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f2: one-to-many depth fusion of the validator (models/yolov10_3D/val.py:78-102)
+# ---------------------------------------------------------------------------------------------------------
+def box_iou_xyxy(b1, b2, eps=1e-7):
+    """utils/metrics.py box_iou: (N, 4) x (M, 4) -> (N, M), float32 in the reference's operation order"""
+    (a1, a2), (c1, c2) = b1.unsqueeze(1).chunk(2, 2), b2.unsqueeze(0).chunk(2, 2)
+    inter = (torch.min(a2, c2) - torch.max(a1, c1)).clamp_(0).prod(2)
+    return inter / ((a2 - a1).prod(2) + (c2 - c1).prod(2) - inter + eps)
+
+
+def kde_fuse_depth(predsO, predsM, thres=0.1, iou_thres=0.9, nprop=500):
+    """val.py:78-102 `aggregate_o2m_preds`: predsO (B, K, 37), predsM (B, KM, 37) post-processed rows [xyxy | ... | depth(-4) |
+    depth log-variance(-3) | score(-2) | label(-1)].  For every one-to-one detection: the one-to-many detections with IoU > 0.9 whose
+    label matches and whose depth score exp(-log-variance) exceeds `thres` vote with it on the depth: a gaussian kernel density
+    (sklearn KernelDensity(bandwidth="silverman"): h = (n (d + 2) / 4)^(-1 / (d + 4)) with d = 1 - NOT scaled by the spread of the
+    samples), weights = normalised depth scores, evaluated at `nprop` evenly spaced proposals between the smallest and the largest
+    vote (np.linspace on float32 end points: float32 arithmetic); the most likely proposal (first maximum of the log-density)
+    replaces the depth.  -> fused predsO (copy)"""
+    import numpy as np
+    out = predsO.clone()
+    for i in range(predsO.shape[0]):
+        iou = box_iou_xyxy(predsO[i, :, :4], predsM[i, :, :4])
+        for j in range(predsO.shape[1]):
+            m = iou[j] > iou_thres
+            d = torch.cat((predsO[i, j, -4:-3], predsM[i, m, -4]))
+            u = torch.cat((predsO[i, j, -3:-2], predsM[i, m, -3]))
+            c = torch.cat((predsO[i, j, -1:], predsM[i, m, -1]))
+            s = torch.exp(-u)
+            mask = (s > thres) & (c == predsO[i, j, -1])
+            if int(mask.sum()) > 1:
+                s, d = s[mask], d[mask]
+                w = (s / s.sum()).numpy().astype(np.float64)
+                x = d.numpy().astype(np.float64)
+                h = (len(x) * 3 / 4.0) ** (-1 / 5.0)
+                lo, hi = np.float32(d.min()), np.float32(d.max())
+                step = np.float32((hi - lo) / np.float32(nprop - 1))
+                prop = (np.arange(nprop, dtype=np.float32) * step + lo).astype(np.float32)
+                prop[-1] = hi
+                pp = prop.astype(np.float64)
+                dens = (w[None, :] * np.exp(-0.5 * ((pp[:, None] - x[None, :]) / h) ** 2)).sum(1)
+                out[i, j, -4] = float(prop[int(np.argmax(np.log(dens)))])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f3: image side of KITTIDataset.__getitem__ (data/datasets/kitti.py:132-206): mirror, mixup blend, affine crop, /255
+# ---------------------------------------------------------------------------------------------------------
+def kitti_image_aug(img, img2, flip, trans_inv, out_wh):
+    """img (H, W, 3) uint8 RGB, img2 the mixup partner or None, flip: mirror both left-right (kitti.py:149, 184), blend
+    `Image.blend(img, img2, 0.5)` (:188; Pillow: in1 + alpha * (in2 - in1) in float, truncated to uint8), then
+    `img.transform(resolution, AFFINE, trans_inv, BILINEAR)` (:192-196; Pillow Geometry.c: the output pixel centre (x + .5, y + .5)
+    is mapped through the 2x3 matrix in double precision, a source position outside [0, W) x [0, H) gives 0, otherwise bilinear
+    interpolation around (xin - .5, yin - .5) with clamped neighbours, result truncated to uint8).
+    -> (outH, outW, 3) uint8; the reference's tensor is this / 255 as float32, CHW (:204-205)."""
+    import numpy as np
+    a = np.asarray(img).astype(np.float64)
+    if flip:
+        a = a[:, ::-1]
+    if img2 is not None:
+        b = np.asarray(img2).astype(np.float64)
+        if flip:
+            b = b[:, ::-1]
+        a = np.floor(a + 0.5 * (b - a))
+    h, w, _ = a.shape
+    W, H = int(out_wh[0]), int(out_wh[1])
+    t = np.asarray(trans_inv, np.float64).reshape(2, 3)
+    ys, xs = np.mgrid[0:H, 0:W]
+    xin = t[0, 0] * (xs + 0.5) + t[0, 1] * (ys + 0.5) + t[0, 2]
+    yin = t[1, 0] * (xs + 0.5) + t[1, 1] * (ys + 0.5) + t[1, 2]
+    inside = (xin >= 0) & (xin < w) & (yin >= 0) & (yin < h)
+    xf, yf = xin - 0.5, yin - 0.5
+    x, y = np.floor(xf).astype(np.int64), np.floor(yf).astype(np.int64)
+    dx, dy = (xf - x)[..., None], (yf - y)[..., None]
+    yc, x0, x1 = np.clip(y, 0, h - 1), np.clip(x, 0, w - 1), np.clip(x + 1, 0, w - 1)
+    v1 = a[yc, x0] + (a[yc, x1] - a[yc, x0]) * dx
+    y1 = np.clip(y + 1, 0, h - 1)
+    v2 = a[y1, x0] + (a[y1, x1] - a[y1, x0]) * dx
+    v2 = np.where(((y + 1 >= 0) & (y + 1 < h))[..., None], v2, v1)
+    out = np.floor(v1 + (v2 - v1) * dy).astype(np.uint8)
+    out[~inside] = 0
+    return out
+
+
+def get_affine_transform(center, scale, output_size, inv=False):
+    """kitti_utils.py:423-464 with rot = 0, shift = 0 (the only form the dataset uses, kitti.py:192): the affine map through the
+    three point pairs (crop centre, the point half a crop WIDTH above it, their right-angle companion) -> (output centre, ...).
+    float32 points as the reference builds them, solved in float64 (cv2.getAffineTransform).  -> trans (2, 3) [, trans_inv]"""
+    import numpy as np
+    center = np.asarray(center, np.float64)
+    scale = np.asarray(scale, np.float64) if np.ndim(scale) else np.array([scale, scale], np.float64)
+    src_w, dst_w, dst_h = scale[0], output_size[0], output_size[1]
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    src[1] = center + np.array([0, src_w * -0.5])
+    dst[0] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + np.array([0, dst_w * -0.5], np.float32)
+
+    def third(a, b):
+        d = a - b
+        return b + np.array([-d[1], d[0]], np.float32)
+
+    src[2], dst[2] = third(src[0], src[1]), third(dst[0], dst[1])
+
+    def solve(p, q):
+        A = np.hstack((p.astype(np.float64), np.ones((3, 1))))
+        return np.linalg.solve(A, q.astype(np.float64)).T.copy()
+
+    trans = solve(src, dst)
+    return (trans, solve(dst, src)) if inv else trans

@@ -313,3 +313,63 @@ def test_assignment_does_not_depend_on_padded_row_bound():
         for a, b in zip(outs[0], outs[1]):
             assert torch.equal(a, b)
         assert int(outs[0][1].sum()) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f2 / f3: the callers either side of the hot path, against the reference's own outputs
+# ---------------------------------------------------------------------------------------------------------
+def test_kitti_image_aug_matches_reference_samples():
+    """mirror / mixup blend / affine crop / 255 of KITTIDataset.__getitem__ (Pillow arithmetic) on the device: every pixel of the
+    reference's own samples, as the float tensor AND as uint8 NHWC straight into the stem"""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    from yolov10_3d_amd import kitti
+    z = np.load(os.path.join(GOLDEN, "kitti_aug.npz"))
+    src = [torch.from_numpy(a).to(DEV) for a in z["src"]]
+    W, H = [int(v) for v in z["resolution"]]
+    n = int(z["n"])
+    idx = [[int(v) for v in z[f"s{i}/index"]] for i in range(n)]
+    imgs = [src[i0] for i0, _, _, _ in idx]
+    partners = [src[i1] if mixed else None for _, i1, _, mixed in idx]
+    flips = [bool(f) for _, _, f, _ in idx]
+    tinv = [z[f"s{i}/trans_inv"] for i in range(n)]
+    out = kitti.augment_images(imgs, partners, flips, tinv, (W, H), "float")
+    ref8 = torch.from_numpy(np.stack([z[f"s{i}/img8"] for i in range(n)]))
+    assert torch.equal(out.cpu(), ref8.float() / 255.0)  # the reference's tensor, bit for bit
+    out8 = kitti.augment_images(imgs, partners, flips, tinv, (W, H), "uint8")
+    assert torch.equal(out8.cpu(), ref8.permute(0, 2, 3, 1))
+    # no-mixup batch takes the null-partner path
+    keep = [i for i in range(n) if not idx[i][3]]
+    o2 = kitti.augment_images([imgs[i] for i in keep], [None] * len(keep), [flips[i] for i in keep], [tinv[i] for i in keep], (W, H), "uint8")
+    assert torch.equal(o2.cpu(), ref8.permute(0, 2, 3, 1)[keep])
+    # the uint8 form feeds the stem: same activations as the float tensor
+    y3d.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    stem = M.Conv(3, 16, 3, 2).to(DEV).train()
+    a = stem(out)
+    b = stem(out8.permute(0, 3, 1, 2))
+    assert torch.equal(a, b)
+
+
+def test_kde_depth_fusion_matches_reference():
+    """the validator's one-to-many depth fusion (scikit-learn KernelDensity per detection on the host in the reference) as one launch"""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    from yolov10_3d_amd import kitti
+    g = np.load(os.path.join(GOLDEN, "kde_fusion.npz"))
+    O, Mm, F = (torch.from_numpy(g[k]) for k in ("predsO", "predsM", "fused"))
+    out = kitti.aggregate_o2m_preds(O.to(DEV), Mm.to(DEV)).cpu()
+    fused = F[..., -4] != O[..., -4]
+    assert int(fused.sum()) >= 50
+    other = torch.ones(37, dtype=torch.bool)
+    other[-4] = False
+    assert torch.equal(out[..., other], F[..., other])           # everything but the depth is passed through
+    assert torch.equal(out[..., -4][~fused], F[..., -4][~fused])  # no votes: depth unchanged
+    # the fused depth is one of 500 float32 proposals: the same proposal as the reference (libm exp / log may differ in the last
+    # bit from numpy's, which can move a tied arg-max by one proposal in rare cases)
+    same = out[..., -4] == F[..., -4]
+    assert float(same.float().mean()) >= 0.98, f"{int((~same).sum())} depths differ"
+    rng = (O[..., -4].max() - O[..., -4].min()).item()
+    assert float((out[..., -4] - F[..., -4]).abs().max()) <= rng / 100

@@ -314,3 +314,35 @@ def test_e2e_n2d_320_baseline_config0():
     assert torch.equal(lab.long(), g["post_labels"].long())
     close(sc, g["post_scores"], rtol=1e-6, atol=1e-7)
     close(bx, g["post_boxes"], rtol=1e-6, atol=1e-5)
+
+
+def test_kde_depth_fusion_restatement_matches_reference():
+    """f2: oracle restatement of the validator's one-to-many depth fusion against the reference's own output (bit for bit)"""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "kde_fusion.npz"))  # (carries a string array: not through load_golden)
+    O, M, F = (torch.from_numpy(g[k]) for k in ("predsO", "predsM", "fused"))
+    out = RS.kde_fuse_depth(O, M)
+    assert int((F[..., -4] != O[..., -4]).sum()) >= 50, "the fixture must exercise the fusion"
+    assert torch.equal(out, F)
+
+
+def test_kitti_image_aug_restatement_matches_reference():
+    """f3: mirror / mixup blend / affine crop of KITTIDataset.__getitem__ (Pillow arithmetic) restated in numpy, against the
+    reference's own samples: every pixel of every sample equal; plus the crop matrix from (centre, crop size)"""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "kitti_aug.npz"))
+    src, (W, H) = z["src"], z["resolution"]
+    kinds = set()
+    for i in range(int(z["n"])):
+        i0, i1, flip, mixed = [int(v) for v in z[f"s{i}/index"]]
+        out = RS.kitti_image_aug(src[i0], src[i1] if mixed else None, flip, z[f"s{i}/trans_inv"], (W, H))
+        assert np.array_equal(out, z[f"s{i}/img8"].transpose(1, 2, 0)), f"sample {i}"
+        kinds.add((flip, mixed))
+    assert len(kinds) == 4
+    # un-cropped samples: centre = image centre, crop = image size
+    t, tinv = RS.get_affine_transform(np.array([160.0, 48.0]), np.array([320.0, 96.0]), (W, H), inv=True)
+    assert np.allclose(tinv, z["s0/trans_inv"], atol=1e-9) and np.allclose(t @ np.vstack((tinv, [0, 0, 1])), np.eye(3)[:2], atol=1e-9)

@@ -135,6 +135,197 @@ __global__ void head_decode_kernel(DecL L, float* __restrict__ y, int B) {
   }
 }
 
+// 2D head (Detect.inference head.py:53-79, DFL block.py:59-62, dist2bbox tal.py:315-325): per anchor the expectation of the softmax
+// over the 16 bins of each box side, (lt, rb) distances -> xywh box in pixels, sigmoid class scores.
+// map (B, H, W, 64 + nc) NHWC with channels [4 x 16 DFL bins | nc logits]  ->  y[b][c][a] fp32, c = x, y, w, h, scores
+template <typename T>
+__global__ void head2d_decode_kernel(DecL L, float* __restrict__ y, int B) {
+  constexpr int RM = 16;
+  long total = (long)B * L.A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / L.A), a = (int)(i - (long)b * L.A);
+    int l = 0;
+    for (int k = 1; k < 4; ++k) if (k < L.nl && a >= L.a0[k]) l = k;
+    int r = a - L.a0[l];
+    int hy = r / L.W[l], hx = r - hy * L.W[l];
+    float ax = hx + 0.5f, ay = hy + 0.5f, st = L.stride[l];
+    const T* p = (const T*)L.map[l] + (((long)b * L.H[l] + hy) * L.W[l] + hx) * L.no;
+    const int nc = L.nc;
+    const int C = 4 + nc;
+    float* o = y + (long)b * C * L.A + a;
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float v[RM], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) { v[j] = TT<T>::ld(p + s * RM + j); mx = fmaxf(mx, v[j]); }
+      float se = 0.f, ex = 0.f;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) { float e = expf(v[j] - mx); se += e; ex += e * (float)j; }
+      d[s] = ex / se;
+    }
+    float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    o[0] = (x1 + x2) / 2.f * st;
+    o[(long)L.A] = (y1 + y2) / 2.f * st;
+    o[2L * L.A] = (x2 - x1) * st;
+    o[3L * L.A] = (y2 - y1) * st;
+    for (int c = 0; c < nc; ++c) o[(long)(4 + c) * L.A] = 1.f / (1.f + expf(-TT<T>::ld(p + 4 * RM + c)));
+  }
+}
+
+// ---- f3: image side of KITTIDataset.__getitem__ (data/datasets/kitti.py:132-206) --------------------------------------------------
+// per output pixel: mirror (FLIP_LEFT_RIGHT), mixup blend (Pillow ImagingBlend: in1 + 0.5 * (in2 - in1) in float, truncated), affine
+// crop with bilinear resampling in Pillow's arithmetic (Geometry.c: the pixel centre through the 2x3 matrix in double precision,
+// outside the source -> 0, clamped neighbours, truncation to uint8).  One thread per output pixel, all three bands.
+struct AugP {
+  const unsigned char* const* src;   // [B] (H, W, 3) uint8 RGB
+  const unsigned char* const* src2;  // [B] mixup partner or null entries (may be null altogether)
+  const int* hw;                     // [B][2] source height, width
+  const int* flip;                   // [B]
+  const double* tinv;                // [B][6] output -> source affine map (the dataset's trans_inv)
+  int B, oh, ow, mode;               // mode 0: (B, 3, oh, ow) fp32 = value / 255 (the reference's tensor); 1: (B, oh, ow, 3) uint8
+};
+
+__device__ __forceinline__ double aug_src(const AugP& p, int b, int H, int W, int fl, int y, int x, int band) {
+  const int xs = fl ? W - 1 - x : x;
+  const long o = ((long)y * W + xs) * 3 + band;
+  const unsigned char* s1 = p.src[b];
+  const unsigned char* s2 = p.src2 ? p.src2[b] : nullptr;
+  int a = s1[o];
+  if (s2) {
+    // (UINT8)((int)in1 + alpha * ((int)in2 - (int)in1)) with alpha = 0.5f: float arithmetic, truncation
+    float f = (float)a + 0.5f * (float)((int)s2[o] - a);
+    a = (int)f;
+  }
+  return (double)a;
+}
+
+__global__ __launch_bounds__(256) void kitti_aug_kernel(AugP p, void* __restrict__ out) {
+  const long total = (long)p.B * p.oh * p.ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ((long)p.oh * p.ow));
+    const int r = (int)(i - (long)b * p.oh * p.ow);
+    const int oy = r / p.ow, ox = r - oy * p.ow;
+    const int H = p.hw[b * 2], W = p.hw[b * 2 + 1], fl = p.flip[b];
+    const double* t = p.tinv + b * 6;
+    const double xc = ox + 0.5, yc = oy + 0.5;
+    double xin = t[0] * xc + t[1] * yc + t[2];
+    double yin = t[3] * xc + t[4] * yc + t[5];
+    int v[3] = {0, 0, 0};
+    if (!(xin < 0.0 || xin >= (double)W || yin < 0.0 || yin >= (double)H)) {
+      xin -= 0.5;
+      yin -= 0.5;
+      const int x = xin < 0.0 ? (int)floor(xin) : (int)xin, y = yin < 0.0 ? (int)floor(yin) : (int)yin;
+      const double dx = xin - x, dy = yin - y;
+      const int yc0 = y < 0 ? 0 : (y >= H ? H - 1 : y);
+      const int x0 = x < 0 ? 0 : (x >= W ? W - 1 : x), x1 = x + 1 < 0 ? 0 : (x + 1 >= W ? W - 1 : x + 1);
+      const bool y1ok = y + 1 >= 0 && y + 1 < H;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double a0 = aug_src(p, b, H, W, fl, yc0, x0, c), a1 = aug_src(p, b, H, W, fl, yc0, x1, c);
+        double v1 = a0 + (a1 - a0) * dx, v2 = v1;
+        if (y1ok) {
+          const double b0 = aug_src(p, b, H, W, fl, y + 1, x0, c), b1 = aug_src(p, b, H, W, fl, y + 1, x1, c);
+          v2 = b0 + (b1 - b0) * dx;
+        }
+        v[c] = (int)(unsigned char)(v1 + (v2 - v1) * dy);
+      }
+    }
+    if (p.mode == 0) {
+      float* o = (float*)out + (long)b * 3 * p.oh * p.ow + r;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[(long)c * p.oh * p.ow] = (float)v[c] / 255.0f;
+    } else {
+      unsigned char* o = (unsigned char*)out + i * 3;
+      o[0] = (unsigned char)v[0]; o[1] = (unsigned char)v[1]; o[2] = (unsigned char)v[2];
+    }
+  }
+}
+
+// ---- f2: one-to-many depth fusion of the validator (models/yolov10_3D/val.py:78-102) -------------------------------------------------
+// one block per one-to-one detection: collect the votes (itself + matching one-to-many rows, in index order), then the weighted
+// gaussian kernel density at NPROP proposals (double precision, as scikit-learn), first maximum of the log-density
+__global__ __launch_bounds__(256) void kde_fusion_kernel(const float* __restrict__ O, const float* __restrict__ M, float* __restrict__ out, int K, int KM,
+                                                         int C, float thres, float iou_thres, int nprop) {
+  extern __shared__ float sm[];       // (one dynamic-LDS symbol per translation unit: float[], viewed as doubles here; 16-byte aligned)
+  double* xs = (double*)sm;           // [KM + 1] votes
+  double* ws = xs + KM + 1;           // [KM + 1] weights
+  double* bv = ws + KM + 1;           // [256]
+  int* bi = (int*)(bv + 256);         // [256]
+  __shared__ int nv;
+  __shared__ float s_lo, s_hi;
+  const int b = blockIdx.y, j = blockIdx.x;
+  const float* o = O + ((long)b * K + j) * C;
+  float* dst = out + ((long)b * K + j) * C;
+  for (int c = threadIdx.x; c < C; c += 256) dst[c] = o[c];
+  if (threadIdx.x == 0) {
+    const float eps = 1e-7f;
+    const float ax1 = o[0], ay1 = o[1], ax2 = o[2], ay2 = o[3], lab = o[C - 1];
+    const float areaA = (ax2 - ax1) * (ay2 - ay1);
+    int n = 0;
+    float ssum = 0.f, lo = 0.f, hi = 0.f;
+    auto vote = [&](float d, float u, float c) {
+      const float s = expf(-u);
+      if (s > thres && c == lab) {
+        xs[n] = (double)d;
+        ws[n] = (double)s;  // normalised below with the float32 sum, as the reference
+        ssum = n == 0 ? s : ssum + s;
+        lo = n == 0 ? d : fminf(lo, d);
+        hi = n == 0 ? d : fmaxf(hi, d);
+        ++n;
+      }
+    };
+    vote(o[C - 4], o[C - 3], lab);
+    for (int m = 0; m < KM; ++m) {
+      const float* q = M + ((long)b * KM + m) * C;
+      float iw = fminf(ax2, q[2]) - fmaxf(ax1, q[0]), ih = fminf(ay2, q[3]) - fmaxf(ay1, q[1]);
+      iw = iw < 0.f ? 0.f : iw;
+      ih = ih < 0.f ? 0.f : ih;
+      const float inter = iw * ih;
+      const float iou = inter / (areaA + (q[2] - q[0]) * (q[3] - q[1]) - inter + eps);
+      if (iou > iou_thres) vote(q[C - 4], q[C - 3], q[C - 1]);
+    }
+    for (int k = 0; k < n; ++k) ws[k] = (double)((float)ws[k] / ssum);
+    nv = n;
+    s_lo = lo;
+    s_hi = hi;
+  }
+  __syncthreads();
+  const int n = nv;
+  if (n <= 1) return;  // uniform
+  const double h = pow((double)n * 3.0 / 4.0, -0.2);
+  const float lo = s_lo, hi = s_hi;
+  const float step = (hi - lo) / (float)(nprop - 1);  // np.linspace on float32 end points
+  double best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int k = threadIdx.x; k < nprop; k += 256) {
+    const float pf = k == nprop - 1 ? hi : (float)k * step + lo;
+    const double pp = (double)pf;
+    double dens = 0.0;
+    for (int t = 0; t < n; ++t) {
+      const double z = (pp - xs[t]) / h;
+      dens += ws[t] * exp(-0.5 * z * z);
+    }
+    const double ld = log(dens);
+    if (ld > best) { best = ld; besti = k; }  // k ascends per thread: first maximum
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = besti;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const double v2 = bv[threadIdx.x + s];
+      const int i2 = bi[threadIdx.x + s];
+      if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) { bv[threadIdx.x] = v2; bi[threadIdx.x] = i2; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int k = bi[0];
+    dst[C - 4] = k == nprop - 1 ? hi : (float)k * step + lo;
+  }
+}
+
 // preds y (B, C, A) fp32 with `nc` score rows first: reg (B,K,C-nc), scores (B,K), labels (B,K) int64
 // hi-res maps, stage 1: block (seg, b) scores the anchors of its segment (max over classes) in LDS and keeps their K best
 __global__ __launch_bounds__(256) void postprocess_seg_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first, int seglen,
@@ -344,6 +535,25 @@ int y3d_head3d_decode(int dtype, int nl, const void* const* maps, const int* H, 
   return Y3D_OK;
 }
 
+int y3d_head2d_decode(int dtype, int nl, const void* const* maps, const int* H, const int* W, const float* strides, int B, int nc,
+                      float* y, void* stream) {
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "head2d_decode: bad dtype");
+  Y3D_CHECK(nl >= 1 && nl <= 4 && nc >= 1, "head2d_decode: 1..4 levels, nc >= 1");
+  DecL L;
+  int a0 = 0;
+  for (int i = 0; i < 4; ++i) {
+    L.map[i] = i < nl ? maps[i] : nullptr;
+    L.H[i] = i < nl ? H[i] : 1; L.W[i] = i < nl ? W[i] : 1; L.a0[i] = a0; L.stride[i] = i < nl ? strides[i] : 1.f;
+    if (i < nl) a0 += H[i] * W[i];
+  }
+  L.nl = nl; L.A = a0; L.nc = nc; L.no = nc + 64;
+  long total = (long)B * a0;
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(head2d_decode_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, L, y, B);
+  else hipLaunchKernelGGL(head2d_decode_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, L, y, B);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
 int y3d_v10_postprocess_scratch_floats(int B, int A, int nc, int max_det) {
   return (size_t)(A + 512 + max_det * (nc + 3)) * 4 <= 160 * 1024 ? 0 : B * A;
 }
@@ -370,6 +580,26 @@ int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det
   (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch,
                      nseg);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_kitti_image_aug(const unsigned char* const* src, const unsigned char* const* src2, const int* hw, const int* flip, const double* trans_inv,
+                        int B, int out_h, int out_w, int mode, void* out, void* stream) {
+  Y3D_CHECK(src && hw && flip && trans_inv && out, "kitti_image_aug: null argument");
+  Y3D_CHECK(B >= 1 && out_h >= 1 && out_w >= 1 && (mode == 0 || mode == 1), "kitti_image_aug: bad sizes / mode");
+  AugP p{src, src2, hw, flip, trans_inv, B, out_h, out_w, mode};
+  hipLaunchKernelGGL(kitti_aug_kernel, dim3(ew_grid((long)B * out_h * out_w)), dim3(256), 0, (hipStream_t)stream, p, out);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_kde_depth_fusion(const float* predsO, int B, int K, const float* predsM, int KM, int C, float thres, float iou_thres, int nprop,
+                         float* out, void* stream) {
+  Y3D_CHECK(predsO && predsM && out && B >= 1 && K >= 1 && KM >= 1 && C >= 8 && nprop >= 2, "kde_depth_fusion: bad arguments");
+  size_t sm = (size_t)(2 * (KM + 1) + 256) * sizeof(double) + 256 * sizeof(int);
+  Y3D_CHECK(sm <= 64 * 1024, "kde_depth_fusion: %d one-to-many rows do not fit LDS", KM);
+  hipLaunchKernelGGL(kde_fusion_kernel, dim3(K, B), dim3(256), sm, (hipStream_t)stream, predsO, predsM, out, K, KM, C, thres, iou_thres, nprop);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

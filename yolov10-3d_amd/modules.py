@@ -593,17 +593,21 @@ class Detect(nn.Module):
         return ys
 
     def inference(self, ys):
-        """head.py:53-79: (B, 4+nc, A): xywh px boxes + sigmoid scores"""
-        B = ys[0].shape[0]
-        cat_ = torch.cat([y.permute(0, 2, 3, 1).reshape(B, -1, self.no) for y in ys], 1).float().permute(0, 2, 1)
-        anc, st = make_anchors([y.shape[2:] for y in ys], self.stride.tolist(), ys[0].device)
-        anc, st = anc.t(), st.t()
-        box, cls = cat_.split((self.reg_max * 4, self.nc), 1)
-        d = self.dfl(box)
-        lt, rb = d.split([2, 2], 1)
-        x1y1, x2y2 = anc.unsqueeze(0) - lt, anc.unsqueeze(0) + rb
-        dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st
-        return torch.cat((dbox, cls.sigmoid()), 1), ys
+        """head.py:53-79: (B, 4+nc, A) fp32: xywh px boxes (DFL expectation + dist2bbox) + sigmoid scores - one HIP launch over the
+        per-level NHWC maps (`y3d_head2d_decode`)"""
+        import ctypes
+        if self.reg_max != 16:
+            raise NotImplementedError("the DFL decode kernel is built for reg_max = 16")
+        B, nl = ys[0].shape[0], len(ys)
+        if not ys[0].is_cuda:
+            raise Y3DError("Detect.inference runs on the HIP kernel of post.hip: head maps must live on a HIP device")
+        ms = [y if (y.dtype == ys[0].dtype and ops.px_dense(y) and y.stride(3) == self.no) else ops._dense_any(y, ys[0].dtype) for y in ys]
+        A = sum(y.shape[2] * y.shape[3] for y in ms)
+        out = torch.empty(B, 4 + self.nc, A, dtype=torch.float32, device=ms[0].device)
+        ops.lib().head2d_decode(ops.code(ms[0].dtype), nl, (ctypes.c_void_p * nl)(*[y.data_ptr() for y in ms]),
+                                (ctypes.c_int * nl)(*[y.shape[2] for y in ms]), (ctypes.c_int * nl)(*[y.shape[3] for y in ms]),
+                                (ctypes.c_float * nl)(*[float(s) for s in self.stride.tolist()[:nl]]), B, self.nc, out.data_ptr(), ops.stream())
+        return out, ys
 
     def forward(self, x):
         y = self.forward_feat(x, self.cv2, self.cv3)
