@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolov10s_3D.yaml")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--weights", default="full", choices=["full", "fp8"],
+                    help="fp8: conv weights as OCP e4m3 codes with per-output-channel power-of-two scales (BASELINE configs[4]; csrc/fp8w.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--infer-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (rehearsal of the N>1 path on one GPU)")
@@ -160,6 +162,8 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     y3d.set_compute_dtype(dtype)
+    if args.weights == "fp8":
+        y3d.set_weight_quant("fp8")
     torch.manual_seed(0)
     model = y3d.YOLOv10_3DDetectionModel(args.model).to(dev).train()
     from yolov10_3d_amd.optim import ModelEMA, build_optimizer
@@ -292,8 +296,8 @@ def main():
         out = {
             "metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"YOLOv10-S + 3D head ({args.model}), {S}x{S}, {args.dtype}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
+            "vs_baseline": None, "dtype": args.dtype if args.weights == "full" else "fp8w", "data": "synthetic",
+            "config": {"workload": f"{args.model} (3D head), {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' on fp8 e4m3 conv weights'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
             "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None,
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],

@@ -49,6 +49,14 @@ int y3d_pack_weight_dgrad(int dtype, const float* w_oihw, void* out, int Cout, i
  * weight {src fp32 OIHW, dst, a, b, c, taps, Kpad, mode}; mode 0 = forward layout (a = Cout, b = Cin/g, c = padded Cin/g),
  * mode 1 = data-gradient layout (a = groups, b = Cout/g, c = Cin/g); chunk tables as in the optimizer kernels below */
 int y3d_mt_pack_weights(int dtype, const int64_t* desc, const int* chunk_tensor, const int* chunk_off, int nchunks, int chunk, void* stream);
+/* fp8 conv weights (fp8w.hip; BASELINE configs[4], no reference counterpart): OCP e4m3fn codes with one power-of-two scale per
+ * output channel, scale = 2^ceil(log2(absmax / 448)).  MANY weights in one launch: desc is a DEVICE array of 6 int64 per weight
+ * {src fp32 (rows, K), w_eff fp32 (rows, K) or 0, codes uint8 (rows, K) or 0, scale fp32 (rows), rows, K}, row_begin (ntensors) the
+ * first global row of each weight, nrows their total.  w_eff = value(code) * scale is exactly representable in bf16, so the bf16
+ * matrix-core kernels compute fp8-weight products exactly when they pack w_eff instead of the master weight. */
+int y3d_mt_fp8w_quantize(const int64_t* desc, const int* row_begin, int ntensors, int nrows, void* stream);
+/* codes (rows, K) + scale (rows) -> fp32 weights (loading a 1-byte-per-weight checkpoint) */
+int y3d_fp8w_dequantize(const uint8_t* codes, const float* scale, float* w, int rows, int K, void* stream);
 int y3d_conv_kpad(int dtype, int k_total);
 /* number of BatchNorm partial rows of the generic implicit-GEMM kernel: ceil(B*Ho*Wo / 128) */
 int y3d_conv_stat_blocks(int B, int Ho, int Wo);

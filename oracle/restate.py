@@ -1030,3 +1030,30 @@ def get_affine_transform(center, scale, output_size, inv=False):
 
     trans = solve(src, dst)
     return (trans, solve(dst, src)) if inv else trans
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp8 weights (BASELINE configs[4]; no reference counterpart: the build's own format, csrc/fp8w.hip)
+# ---------------------------------------------------------------------------------------------------------
+def fp8w_quantize(w):
+    """w (Cout, ...) fp32 -> (codes uint8 same shape, scale (Cout,), w_eff fp32): OCP e4m3fn codes (torch.float8_e4m3fn: round to
+    nearest even) of w / scale with scale = 2^ceil(log2(absmax / 448)) per output channel (1 for an all-zero row)."""
+    rows = w.shape[0]
+    flat = w.detach().float().reshape(rows, -1)
+    amax = flat.abs().amax(1)
+    scale = torch.where(amax > 0, torch.exp2(torch.ceil(torch.log2(amax.double() / 448.0))).float(), torch.ones_like(amax))
+    q = (flat / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    w_eff = (q.float() * scale[:, None]).reshape(w.shape)
+    return q.view(torch.uint8).reshape(w.shape), scale, w_eff
+
+
+def fp8w_state(spec, state):
+    """a copy of the oracle state with every dense / grouped conv weight that is followed by BatchNorm replaced by its fp8 value
+    (the weights `y3d.set_weight_quant("fp8")` multiplies with); depth-wise filters and the heads' final projections untouched"""
+    out = {}
+    for k, v in state.items():
+        if k.endswith(".conv.weight") and v.dim() == 4 and k[: -len("conv.weight")] + "bn.weight" in state and not (v.shape[1] == 1 and v.shape[0] > 1):
+            out[k] = fp8w_quantize(v)[2]
+        else:
+            out[k] = v
+    return out

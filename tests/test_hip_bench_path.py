@@ -373,3 +373,112 @@ def test_kde_depth_fusion_matches_reference():
     assert float(same.float().mean()) >= 0.98, f"{int((~same).sum())} depths differ"
     rng = (O[..., -4].max() - O[..., -4].min()).item()
     assert float((out[..., -4] - F[..., -4]).abs().max()) <= rng / 100
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp8 weights (BASELINE configs[4])
+# ---------------------------------------------------------------------------------------------------------
+def test_fp8w_quantizer_bit_exact_vs_torch_float8():
+    """codes / per-channel power-of-two scales / effective weights of csrc/fp8w.hip against torch.float8_e4m3fn (round to nearest even)"""
+    from oracle import restate as RS
+    L = y3d.lib()
+    torch.manual_seed(3)
+    ws = [torch.randn(24, 16, 3, 3) * 0.1, torch.randn(7, 40, 1, 1) * 3.0, torch.randn(130, 9) * 1e-4, torch.zeros(4, 8, 1, 1)]
+    ws[0][3] = 0                      # an all-zero row
+    ws[1][2, :5, 0, 0] = torch.tensor([448.0, -448.0, 449.0, 1e-9, -0.0])
+    ws[2][5] *= 1e6                   # rows of very different magnitude
+    dev = [w.to(DEV).contiguous() for w in ws]
+    outs = [(torch.empty_like(w), torch.empty(w.shape, dtype=torch.uint8, device=DEV), torch.empty(w.shape[0], device=DEV)) for w in dev]
+    desc, rb, r = [], [], 0
+    for w, (e, c, s) in zip(dev, outs):
+        desc += [w.data_ptr(), e.data_ptr(), c.data_ptr(), s.data_ptr(), w.shape[0], w[0].numel()]
+        rb.append(r)
+        r += w.shape[0]
+    # (the tables must outlive the launch: a temporary freed right after .data_ptr() hands its block to the next allocation)
+    t_desc, t_rb = torch.tensor(desc, dtype=torch.int64, device=DEV), torch.tensor(rb, dtype=torch.int32, device=DEV)
+    L.mt_fp8w_quantize(t_desc.data_ptr(), t_rb.data_ptr(), len(ws), r, ops.stream())
+    for w, (e, c, s) in zip(ws, outs):
+        c_ref, s_ref, e_ref = RS.fp8w_quantize(w)
+        assert torch.equal(s.cpu(), s_ref)
+        cc = c.cpu()
+        same = cc == c_ref
+        # +0 / -0 codes of values that round to zero may differ in the sign bit only
+        assert bool((same | (((cc | c_ref) & 0x7f) == 0)).all()), f"{int((~same).sum())} codes differ"
+        assert torch.equal(e.cpu(), e_ref)
+        assert torch.equal(e.cpu().bfloat16().float(), e.cpu()), "effective weights must be exact in bf16"
+        back = torch.empty_like(e)
+        L.fp8w_dequantize(c.data_ptr(), s.data_ptr(), back.data_ptr(), w.shape[0], w[0].numel(), ops.stream())
+        assert torch.equal(back, e)
+
+
+def test_fp8w_model_matches_oracle_on_quantized_weights():
+    """the tiny 3D model with `set_weight_quant("fp8")` (exact-fp32 compute) == the CPU oracle run on the fp8-valued weights: loss
+    items and gradients within the 1e-3 of the fp32 parity mode (the gradient of a quantised weight goes to its fp32 master)"""
+    from test_hip_modules import TINY, _tiny_cfg, check, grad_floor
+    from oracle import restate as RS
+    g = load_golden("e2e_tiny3d_s")
+    cfg = _tiny_cfg("yolov10s_3D.yaml", **TINY, kernel_size_1=3, kernel_size_2=3, num_scales=3)
+    spec = RS.build_spec(cfg)
+    st = RS.fp8w_state(spec, {k: v.clone() for k, v in g["state"].items()})
+    nq = sum(1 for k in st if not torch.equal(st[k], g["state"][k]))
+    assert nq >= 60, f"only {nq} weights were quantised"
+    for v in st.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    for k in list(st):
+        if "running" in k or "num_batches" in k:
+            st[k] = st[k].detach()
+    batch = {k: v for k, v in g["batch"].items()}
+    batch["img"] = g["img"]
+    preds = RS.forward(spec, st, g["img"], True)
+    loss_o, items_o, _ = RS.loss3d(preds, batch, RS.model_strides(spec), 3)
+    loss_o.backward()
+    y3d.set_compute_dtype(torch.float32)
+    y3d.set_weight_quant("fp8")
+    try:
+        model = y3d.YOLOv10_3DDetectionModel(cfg)
+        model.load(g["state"])
+        model = model.to(DEV).train()
+        dbatch = {k: v.to(DEV) for k, v in batch.items()}
+        loss, items = model(dbatch)
+        loss.backward()
+        check(items, items_o.detach(), 1e-3, "loss items (fp8 weights)")
+        # not the unquantised result: the mode is on
+        assert float((items.cpu() - g["items"]).abs().max()) > 1e-3 * float(g["items"].abs().max())
+        named = dict(model.named_parameters())
+        grads = {k: st[k].grad for k in g["grads"] if st[k].grad is not None}
+        gf = grad_floor(grads)
+        for k, gv in grads.items():
+            check(named[k].grad, gv, 5e-3, f"grad {k}", gf)
+        # torch-side weight update is seen (shadow + packs follow the master's version), 1-byte state dict round trip
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.25)
+        loss2, items2 = model(dbatch)
+        sd8 = y3d.tasks.fp8_state_dict(model)
+        assert len(sd8) >= 60 and all(c.dtype == torch.uint8 for c, _ in sd8.values())
+        y3d.set_weight_quant(None)
+        m3 = y3d.tasks.load_fp8_state_dict(y3d.YOLOv10_3DDetectionModel(cfg).to(DEV), sd8)
+        n3 = dict(m3.named_parameters())
+        for k, (c, s_) in sd8.items():
+            ref = RS.fp8w_quantize(named[k].detach().cpu())[2]
+            assert torch.equal(n3[k].detach().cpu(), ref), k
+        assert torch.isfinite(items2).all() and not torch.allclose(items2, items)
+    finally:
+        y3d.set_weight_quant(None)
+
+
+def test_fp8w_bf16_conv_products_are_exact():
+    """bf16 kernels on fp8-valued weights: with integer activations every product and partial sum is exact, so the bf16 conv on
+    w_eff equals the fp32 host conv on w_eff bit for bit - the 'fp8 weight x bf16 activation' MFMA the format stands for"""
+    from oracle import restate as RS
+    gen = torch.Generator().manual_seed(9)
+    B, Cin, Cout, H, W = 4, 128, 256, 16, 16
+    x = _sparse_int((B, Cin, H, W), gen, 0.25)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
+    _, scale, w_eff = RS.fp8w_quantize(w)
+    y3d.set_compute_dtype(torch.bfloat16)
+    y, _, _, _ = _conv_abi(x, w_eff, 1, _sparse_int((B, Cout, H, W), gen))
+    y_ref = F.conv2d(x, w_eff, padding=1)
+    # the fp32 sums of <= 1152 products with 4 significant bits each at one exponent per row are exact; the bf16 store rounds once
+    assert torch.equal(y, y_ref.bfloat16().float())

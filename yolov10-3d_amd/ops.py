@@ -215,7 +215,81 @@ class _PackRegistry:
         return e["dst"]
 
 
-PACK_FWD, PACK_DGRAD = _PackRegistry(0), _PackRegistry(1)
+class _QuantRegistry:
+    """fp8 (e4m3fn, per-output-channel power-of-two scale) shadows of the conv weights — the `fp8w` weight mode (csrc/fp8w.hip).
+
+    For every registered fp32 master weight (identified by address + shape) it keeps `w_eff` (fp32, what the kernels pack and
+    multiply: exactly representable in bf16), the 1-byte codes and the scales.  All shadows are refreshed by ONE multi-tensor
+    launch the first time a weight is looked up after the fused optimizer moved the weight epoch; a weight changed through torch
+    (its version token moved) is refreshed on its own.  `lookup` returns (w_eff, token): the token stands in for the master's
+    version in the pack registries' and the eval caches' keys (the shadow's own counter never moves)."""
+
+    def __init__(self):
+        self.entries, self.epoch, self.tables = {}, None, None
+
+    def _run(self, ents):
+        dev = ents[0]["weff"].device
+        key = tuple(id(e) for e in ents)
+        if self.tables is None or self.tables[0] != key:
+            desc, rb, r = [], [], 0
+            for e in ents:
+                rows, K = e["shape"]
+                desc += [e["src"], e["weff"].data_ptr(), e["codes"].data_ptr(), e["scale"].data_ptr(), rows, K]
+                rb.append(r)
+                r += rows
+            self.tables = (key, torch.tensor(desc, dtype=torch.int64, device=dev), torch.tensor(rb, dtype=torch.int32, device=dev), len(ents), r)
+        _, desc, rb, nt, nrows = self.tables
+        lib().mt_fp8w_quantize(desc.data_ptr(), rb.data_ptr(), nt, nrows, stream())
+
+    def lookup(self, w32, ver=None):
+        ver = w32._version if ver is None else ver
+        rows, K = w32.shape[0], w32[0].numel()
+        key = (w32.data_ptr(), rows, K)
+        e = self.entries.get(key)
+        if e is None:
+            dev = w32.device
+            e = {"src": w32.data_ptr(), "shape": (rows, K), "keep": w32, "weff": torch.empty(w32.shape, dtype=torch.float32, device=dev),
+                 "codes": torch.empty((rows, K), dtype=torch.uint8, device=dev), "scale": torch.empty(rows, dtype=torch.float32, device=dev),
+                 "ver": ver, "count": 0, "seen": WEIGHT_EPOCH}
+            self.entries[key] = e
+            tb, self.tables = self.tables, None
+            self._run([e])
+            self.tables = tb
+            return e["weff"], (WEIGHT_EPOCH, e["count"])
+        e["seen"] = WEIGHT_EPOCH
+        if self.epoch != WEIGHT_EPOCH:
+            self.epoch = WEIGHT_EPOCH
+            for k in [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > _PackRegistry.KEEP]:
+                del self.entries[k]
+            self._run(list(self.entries.values()))
+            for v in self.entries.values():
+                v["ver"] = None
+        if e["ver"] is None:
+            e["ver"] = ver
+        elif e["ver"] != ver:  # the master was written through torch since the shadow was made
+            e["ver"], e["count"] = ver, e["count"] + 1
+            tb, self.tables = self.tables, None
+            self._run([e])
+            self.tables = tb
+        return e["weff"], (WEIGHT_EPOCH, e["count"])
+
+
+PACK_FWD, PACK_DGRAD, QUANT = _PackRegistry(0), _PackRegistry(1), _QuantRegistry()
+WEIGHT_QUANT = None  # None | "fp8": conv (+BatchNorm) weights as e4m3fn codes with per-output-channel power-of-two scales
+
+
+def set_weight_quant(mode):
+    """None (default) or "fp8": BASELINE configs[4].  Applies to the weights of Conv modules (dense / grouped convs followed by
+    BatchNorm: 99 % of the parameters); depth-wise filters and the heads' final 1x1 projections (with bias) stay in full precision."""
+    global WEIGHT_QUANT
+    if mode not in (None, "fp8"):
+        raise ValueError("weight quantisation mode must be None or 'fp8'")
+    WEIGHT_QUANT = mode
+    bump_param_epoch()
+
+
+def weight_quant():
+    return WEIGHT_QUANT
 PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv packing launches instead of the registry
 
 
@@ -238,7 +312,7 @@ def _timed(key, launch):
 
 
 def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True, pack_cache=True,
-                 ver=None):
+                 ver=None, quant=True):
     """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs.
     ver = (weights token, all-tensors token) of a stacked view (StackedConvs), None for tensors that carry their own counters."""
     L = lib()
@@ -248,6 +322,10 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     st = stream()
     dev = x.device
     B, Cin, H, W = x.shape
+    if WEIGHT_QUANT and quant and not (g > 1 and g == Cin and g == w32.shape[0]):
+        # fp8w mode: the kernels pack and multiply the fp8-valued shadow of the weight; the master keeps receiving the gradient
+        w32, qtok = QUANT.lookup(w32, ver[0] if ver is not None else None)
+        ver = ((qtok,), (qtok,) + (ver[1] if ver is not None else (g32._version, b32._version, rm._version, rv._version)))
     Cout, Cg_w, kh, kw = w32.shape
     assert kh == k and kw == k and Cin // g == Cg_w, "Conv: weight shape does not match input"
     Ho = (H + 2 * p - k) // s + 1
@@ -266,7 +344,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         wcol = torch.zeros(Cout, 32, dtype=torch.float32, device=dev)
         wcol[:, :27] = w32.detach().permute(0, 2, 3, 1).reshape(Cout, 27)  # column (r*3+q)*3+ci
         z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache,
-                                     pack_cache=False)  # wcol is a temporary
+                                     pack_cache=False, quant=False)  # wcol is a temporary (built from the already quantised stem weight)
         return z, (cfg + ("stem",) if cfg is not None else None), saved
     dw = g > 1 and g == Cin and g == Cout
     # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
@@ -332,7 +410,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     else:
         L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
     if not bn_apply:  # the consumer applies BatchNorm + activation itself (FusedConvBNProjFn): hand back the pre-BN tensor
-        cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act))
+        cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
         return y, cfg, (xin, w32, y, stats, None)
     z = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
     rr = None
@@ -341,7 +419,8 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         assert rr.shape == z.shape, "residual shape mismatch"
     L.bn_act_fwd(dt, y.data_ptr(), Cout, stats[2].data_ptr(), stats[3].data_ptr(), int(act), res_mode,
                  rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), Cout, M, Cout, st)
-    cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act))
+    # [17]: version token of the weights as packed (stacked views / fp8 shadows carry their identity outside the tensor's own counter)
+    cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
 
 
@@ -350,8 +429,9 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None, w
     (the one-to-one head sees a detached input, reference head.py:820)."""
     L = lib()
     xin, w32, y, stats, rr = saved
-    stem = len(cfg) > 17
+    stem = cfg[-1] == "stem"
     B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg[:17]
+    wver = cfg[17]
     if not training:
         raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
     if pre is not None:  # (dy, dgb): the BatchNorm part was done by the caller (FusedConvBNProjFn)
@@ -386,8 +466,9 @@ def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, wver=None):
     """data and weight gradients of the conv given dy (gradient wrt its pre-BatchNorm output)"""
     L = lib()
     xin, w32, y, stats, rr = saved
-    stem = len(cfg) > 17
+    stem = cfg[-1] == "stem"
     B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg[:17]
+    wver = cfg[17]
     dt = code(dtype)
     st = stream()
     dev = dy.device

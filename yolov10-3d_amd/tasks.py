@@ -18,6 +18,8 @@ from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
+
+from ._lib import Y3DError
 import yaml
 
 from . import modules as M
@@ -155,6 +157,49 @@ def folded_state_dict(model):
                 w, b = fuse_conv_and_bn(m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.eps)
                 out[name + ".conv.weight"], out[name + ".conv.bias"] = w, b
     return out
+
+
+def fp8_state_dict(model):
+    """The 1-byte weight store of the `fp8w` mode (BASELINE configs[4]; csrc/fp8w.hip): {conv key: (codes uint8 OIHW, scale fp32 (Cout,))}
+    for every dense / grouped Conv of the model (depth-wise filters and everything else stay in `state_dict()` form).  The codes are
+    what `y3d.set_weight_quant("fp8")` multiplies with: value(code) * scale."""
+    from . import ops
+    out = {}
+    seen = set()
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, Conv) and not (m.g > 1 and m.g == m.conv.in_channels and m.g == m.conv.out_channels):
+                w = m.conv.weight.detach()
+                if not w.is_cuda:
+                    raise Y3DError("fp8_state_dict: the quantiser runs on the HIP device")
+                if w.data_ptr() in seen:
+                    continue
+                seen.add(w.data_ptr())
+                w32 = w.float().contiguous()
+                rows, K = w32.shape[0], w32[0].numel()
+                codes = torch.empty(w32.shape, dtype=torch.uint8, device=w.device)
+                scale = torch.empty(rows, dtype=torch.float32, device=w.device)
+                desc = torch.tensor([w32.data_ptr(), 0, codes.data_ptr(), scale.data_ptr(), rows, K], dtype=torch.int64, device=w.device)
+                rb = torch.zeros(1, dtype=torch.int32, device=w.device)
+                ops.lib().mt_fp8w_quantize(desc.data_ptr(), rb.data_ptr(), 1, rows, ops.stream())
+                out[name + ".conv.weight"] = (codes, scale)
+    return out
+
+
+def load_fp8_state_dict(model, fp8_sd):
+    """inverse of fp8_state_dict: writes value(code) * scale into the named conv weights (in place)"""
+    from . import ops
+    named = dict(model.named_parameters())
+    with torch.no_grad():
+        for k, (codes, scale) in fp8_sd.items():
+            p = named[k]
+            if not p.is_cuda:
+                raise Y3DError("load_fp8_state_dict: the model must live on the HIP device")
+            w = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+            ops.lib().fp8w_dequantize(codes.to(p.device).contiguous().data_ptr(), scale.to(p.device).float().contiguous().data_ptr(), w.data_ptr(),
+                                      p.shape[0], p[0].numel(), ops.stream())
+            p.copy_(w)
+    return model
 
 
 def initialize_weights(model):
