@@ -124,6 +124,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
   // `wave` and everything derived from it is wave-uniform: scalar registers (the compiler cannot prove threadIdx.x >> 6 uniform)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
+  const int slot = wave & 3;  // DMA issue point of this wave inside its half of the stage (Y3D_STAGGER)
   const int ltid = tid & (LH - 1);
   const int wimg = wp / WPI, wrow0 = (wp % WPI) * 8;
   const int nslab = p.Cg >> 5;             // >= 2 (launcher)
@@ -296,7 +297,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         // wave is held meanwhile (measured: 250-450 cycles per instruction when all eight waves issue together), so the two waves
         // of a SIMD issue at DIFFERENT times: the halo wave here, while its partner runs half 0's MFMAs; the weight wave between
         // the halves, while this one computes --------------------------------------------------------------------------------------
-#ifndef Y3D_PROBE_NODMA
+#if !defined(Y3D_PROBE_NODMA) && !defined(Y3D_STAGGER)
         if (HROLE) {
 #ifndef Y3D_PROBE_NOHALO
           __builtin_amdgcn_sched_barrier(0);  // confine the address arithmetic to the top of the stage, where the live set is smallest
@@ -308,6 +309,24 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         TRC(1);
         // ---- half 0: pixel rows 0..3 while rows 4..7 of this tap are fetched --------------------------------------------------------
         load_b(fb[1], hb_cur, t, 1);
+#ifdef Y3D_STAGGER
+        // The four halo waves (one per SIMD) issue their DMA instructions at FOUR different points of half 0 - before MFMA group
+        // `slot` = wave & 3 - and the four weight waves likewise inside half 1: eight instructions arriving together queue behind
+        // each other in the CU's one LDS-DMA path and hold every issuing wave for 450-570 cycles of a 1500-cycle stage (probe trace);
+        // spread over the stage each finds the path nearly free.
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if (HROLE && ct == slot) {
+            __builtin_amdgcn_sched_barrier(0);
+            halo_stage(htile, hs, hb_tgt, t);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ct][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[0][i], acc[ct][i], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
+#else
         __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together and ahead of the partner wave's VALU / DMA issue (+2 %)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
@@ -320,12 +339,13 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
 #endif
           }
         __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- half 1: rows 4..7 while the first fragments of the next stage are fetched (its tap was published one barrier ago);
         // the weight fragments are refreshed IN PLACE, each right behind the last MFMA that reads it (no second buffer: the
         // 128 accumulators leave no room for one) ------------------------------------------------------------------------------------
         TRC(2);
         __builtin_amdgcn_sched_barrier(0);  // keep half 1's fragment loads out of half 0: both sets live at once would spill
-#ifndef Y3D_PROBE_NODMA
+#if !defined(Y3D_PROBE_NODMA) && !defined(Y3D_STAGGER)
         if (!HROLE) {
 #ifndef Y3D_PROBE_NOWEIGHT
           __builtin_amdgcn_sched_barrier(0);
@@ -340,6 +360,15 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         if (t < 8) load_b(fb[0], hb_cur, t + 1, 0); else if (!last) load_b(fb[0], hb_nxt, 0, 0);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
+#ifdef Y3D_STAGGER
+          if (!HROLE && ct == slot) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int t2 = t + D;
+            if (t2 < 9) issue_w(cur, k, t2, (kr + t2) & 3);
+            else issue_w(wtile, wslab, t2 - 9, (kr + t2) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
 #ifdef Y3D_PROBE_NOMFMA

@@ -73,10 +73,15 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ ali
   __shared__ float sv[256];
   __shared__ int si[256];
   __shared__ int chosen[16];
-  const int bg = blockIdx.x, b = bg / n;
+  // block id -> (row g, image b) with the ROW as the slow index: the rows in use (g < n_used, known on the device only) are the first
+  // B * n_used blocks of the grid, so the dispatcher spreads them over the whole chip; with the image as the slow index the few
+  // working blocks of every image sat next to 64 - n_used empty ones and piled up on a fraction of the CUs (2x slower)
+  const int B_ = gridDim.x / n;
+  const int g_ = blockIdx.x / B_, b = blockIdx.x - g_ * B_;
+  const int bg = b * n + g_;
   const float* r = rec + (long)bg * GTW;
   int* out = cand + (long)bg * k;
-  if (bg - b * n >= rows_used(n_used, n)) return;  // never read: resolve_kernel stops at the same bound
+  if (g_ >= rows_used(n_used, n)) return;  // never read: resolve_kernel stops at the same bound
   if (r[G_VALID] == 0.f) {
     if (threadIdx.x < k) out[threadIdx.x] = -1;
     return;
