@@ -84,7 +84,7 @@ def main():
     if wide:
         avg, name, grid, s, per, lo, hi, n = wide[0]
         print(f"# headline launch (slowest slot of conv3x3_wide_kernel<16, 0>, the fused head layer-2 forward at P3): avg {avg / 1e3:.1f} us over {n} launches"
-              f" = {966.367641600 / (avg / 1e9) / 1e12:.1f} TFLOP/s at 966.37 GFLOP per launch (B=32, 640x640)")
+              f" = {966.3676416e9 / (avg * 1e-9) / 1e12:.1f} TFLOP/s at 966.37 GFLOP per launch (B=32, 640x640; profiled passes clock lower than the un-profiled bench)")
 
 
 if __name__ == "__main__":

@@ -69,7 +69,7 @@ __device__ __forceinline__ float ciou_f(const float* g, float x21, float y21, fl
 
 // one block per (b, g): k passes of arg-max with (value desc, index asc) order; cand[b][g][j] = anchor index or -1
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ align, const float* __restrict__ rec, int* __restrict__ cand,
-                                                   Levels L, int n, int k, const int* __restrict__ n_used) {
+                                                   Levels L, int n, int k, const int* __restrict__ n_used, int lds_row) {
   __shared__ float sv[256];
   __shared__ int si[256];
   __shared__ int chosen[16];
@@ -87,14 +87,26 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ ali
     return;
   }
   const float* row = align + (long)bg * L.A;
+  // the row is scanned k times: keep it in LDS when it fits (8400 anchors: 33 KB) - one pass over global memory instead of k
+  extern __shared__ float srow[];
+  const bool in_lds = lds_row != 0;
+  if (in_lds) {
+    for (int a = threadIdx.x; a < L.A; a += 256) srow[a] = row[a];
+    __syncthreads();
+  }
   for (int j = 0; j < k; ++j) {
     float bv = -1.f;
     int bi = 0x7fffffff;
     for (int a = threadIdx.x; a < L.A; a += 256) {
-      bool skip = false;
-      for (int t = 0; t < j; ++t) skip |= (chosen[t] == a);
-      if (skip) continue;
-      float v = row[a];
+      float v;
+      if (in_lds) {
+        v = srow[a];  // chosen anchors were overwritten with -2 (metrics are >= 0)
+      } else {
+        bool skip = false;
+        for (int t = 0; t < j; ++t) skip |= (chosen[t] == a);
+        if (skip) continue;
+        v = row[a];
+      }
       if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
     }
     sv[threadIdx.x] = bv;
@@ -108,7 +120,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ ali
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) chosen[j] = si[0];
+    if (threadIdx.x == 0) {
+      chosen[j] = si[0];
+      if (in_lds && si[0] < L.A) srow[si[0]] = -2.f;
+    }
     __syncthreads();
   }
   if (threadIdx.x < k) {

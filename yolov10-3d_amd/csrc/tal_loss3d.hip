@@ -360,7 +360,10 @@ int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   size_t sm = (size_t)n * GTW * sizeof(float);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used);
   else hipLaunchKernelGGL(metric_kernel<float>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used);
-  hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), 0, st, align, rec, cand, L, n, topk, n_used);
+  {
+    const bool fits = (size_t)A * sizeof(float) <= 96 * 1024;  // the metric row in LDS (33.6 KB at 640x640; 1280x1280: 131 KB, global passes)
+    hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), fits ? (size_t)A * sizeof(float) : 0, st, align, rec, cand, L, n, topk, n_used, fits ? 1 : 0);
+  }
   int nblk = cdiv((long)B * A, 256);
   hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, sim, fg_mask, target_gt_idx, pa, po, B, n, A, topk, n_used);
   hipLaunchKernelGGL(scores_kernel, dim3(nblk), dim3(256), 0, st, fg_mask, target_gt_idx, align, rec, pa, po, target_scores, part, B, n, A, nc, 1e-9f);
