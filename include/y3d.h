@@ -179,6 +179,16 @@ int y3d_proj_group_fwd(int dtype, int nb, int cin, const void* x, int64_t xsw, c
                        const float* const* b, const int* couts, void* y, int64_t ysw, int64_t P, void* stream);
 int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t dsw, const int* xoff, const float* const* w,
                             const int* couts, void* dx, int64_t xsw, int64_t P, void* stream);
+/* BatchNorm backward of the conv that feeds a projection group, recomputing dz = dout . W on the matrix cores instead of reading a
+ * materialised gradient tensor (proj_bn_mfma.hip, bf16, cin = 64 / 128; the backward of head.py:633-637 + conv.py:120 for one level):
+ * mode 0: partials [y3d_proj_group_bn_bwd_blocks(P)][C][2] = (sum g, sum g*xhat), g = dz * act'(u)  -> y3d_bn_bwd_finalize;
+ * mode 1: dy = scale * (g - mean_g - xhat * mean_gx).  y_pre: the conv's pre-BatchNorm output (C channels, branch i at xoff[i]),
+ * dout: gradient of the projected map (branch i's couts[i] channels side by side in branch order). */
+int y3d_proj_group_bn_bwd_blocks(int64_t P);
+int y3d_proj_group_bn_bwd(int mode, int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const void* dout, int64_t dsw,
+                          const float* const* w, const int* couts, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* mean_g, const float* mean_gx, int act, float* partials, int nblk, void* dy,
+                          int64_t dysw, int64_t P, int C, void* stream);
 int y3d_proj_group_blocks(int64_t P);
 /* the same projections fused with the BatchNorm (+SiLU) that precedes them: y_pre is the PRE-BatchNorm conv output; the activation
  * act(y_pre * scale + shift) is formed on the fly (forward) / rebuilt (weight gradient) and never stored */

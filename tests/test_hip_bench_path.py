@@ -482,3 +482,40 @@ def test_fp8w_bf16_conv_products_are_exact():
     y_ref = F.conv2d(x, w_eff, padding=1)
     # the fp32 sums of <= 1152 products with 4 significant bits each at one exponent per row are exact; the bf16 store rounds once
     assert torch.equal(y, y_ref.bfloat16().float())
+
+
+@pytest.mark.parametrize("mid,hw,B", [(128, (16, 16), 2), (128, (10, 13), 3), (64, (8, 20), 2)])
+def test_proj_bn_mfma_backward_matches_materialised_path(mid, hw, B):
+    """second head layer's BatchNorm backward recomputing dz = dout . W on the matrix cores (proj_bn_mfma.hip) against the path that
+    materialises dz (projg_bwd_data + bn_act_bwd_reduce / _apply): same input / weight / BatchNorm gradients up to bf16 rounding of
+    the dz tensor the old path stores; pixel counts that are not multiples of the 64-pixel step included"""
+    from test_hip_modules import check
+    y3d.set_compute_dtype(torch.bfloat16)
+    chan = {k + "_c": mid for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    torch.manual_seed(11)
+    head = M.v10Detect3d(3, (64,), False, chan, False, False, False, False, 1, False, False, 3, 3)
+    head.stride = torch.tensor([8.0])
+    head.bias_init()
+    with torch.no_grad():
+        for p_ in head.o2m_heads.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    head = head.to(DEV).train()
+    x = torch.randn(B, 64, *hw, device=DEV)
+    r = [torch.randn(B, 38, *hw, device=DEV) for _ in range(2)]
+    res = {}
+    for flag in (True, False):
+        ops.PROJ_BN_MFMA = flag
+        try:
+            head.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            out = head([xi])
+            assert "_y3d_maps" in out
+            ((out["one2one"][0].float() * r[0]).sum() + (out["one2many"][0].float() * r[1]).sum()).backward()
+            res[flag] = (xi.grad.float().clone(), {k: v.grad.float().clone() for k, v in head.named_parameters() if v.grad is not None})
+        finally:
+            ops.PROJ_BN_MFMA = True
+    check(res[True][0], res[False][0], 2e-2, "dx")
+    assert set(res[True][1]) == set(res[False][1])
+    big = max(float(v.abs().max()) for v in res[False][1].values())
+    for k, v in res[False][1].items():
+        check(res[True][1][k], v, 3e-2, f"grad {k}", floor=1e-3 * big)

@@ -1,0 +1,185 @@
+// BatchNorm backward of the second head layer WITHOUT the 839 MB gradient tensor in between (bf16).
+//
+// Training head, per level (modules.v10Detect3d.forward_train_fused): y2 = grouped 3x3 conv (16 branches x `cin` channels), out =
+// proj_b(SiLU(BN(y2)))  (proj_group.hip: projg_fwd_bn).  Backward so far: projg_bwd_data wrote dz2 = dout . W (839 MB at P3),
+// bn_act_bwd_reduce read y2 + dz2, bn_act_bwd_apply read y2 + dz2 and wrote dy2: 5.0 GB of traffic, 1.3 ms per step at 4.6 TB/s.
+// dz2[px][ch] = sum_o dout[px][o] * W[o][ch] has K = cout <= 24: ONE 16x16x32 MFMA per 16 pixels x 16 channels.  Both BatchNorm
+// passes recompute it from the 31 MB `dout` instead of reading it:
+//   MODE 0 (reduce): partial sums of g = dz2 * act'(u) and g * xhat per channel  (same partial-slab format as bn_act.hip)
+//   MODE 1 (apply):  dy2 = scale * (g - mean(g) - xhat * mean(g * xhat))
+// 2.5 GB instead of 5.0 GB; dz2 is also never rounded to bf16.
+// One workgroup = one branch x a run of pixels, 4 waves x 16 pixels per step.  The MFMA result (lane = 4 pixels x 1 channel) goes
+// through a per-wave LDS tile to the row layout (lane = 1 pixel x 8 channels) in which y2 is loaded and dy2 stored as coalesced
+// 16-byte chunks and the per-channel constants / sums are lane-stationary.
+#include "common.h"
+
+namespace {
+
+constexpr int PB_MAXB = 16;
+
+struct PBP {
+  const bf16_t* y;     // pre-BatchNorm conv output, pixel stride ysw
+  const bf16_t* dout;  // gradient of the projected map, pixel stride dsw
+  bf16_t* dy;          // MODE 1: gradient wrt y, pixel stride dysw
+  float* part;         // MODE 0: [gridDim.x][C][2]
+  const float* w[PB_MAXB];  // [cout][cin] fp32
+  int xoff[PB_MAXB], ooff[PB_MAXB], cout[PB_MAXB];
+  const float *scale, *shift, *mean, *invstd, *mg, *mgx;
+  long ysw, dsw, dysw, P;
+  int cin, C, act, px_per_block;
+};
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(256) void projg_bn_bwd_kernel(PBP p) {
+  constexpr int CIN = NT * 16, LDW = CIN + 4;  // LDS row pitch (floats): +4 keeps rows 16-byte aligned and spreads the four row groups over the banks
+  constexpr int CH = CIN / 8;                  // 16-byte chunks per pixel row of this branch
+  constexpr int PPP = 64 / CH;                 // pixels per pass of a wave in the row layout
+  constexpr int NPASS = 16 / PPP;
+  static_assert(NPASS >= 1 && 64 % CH == 0 && 16 % PPP == 0, "cin must be 32, 64 or 128");
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, lp = lane & 15;
+  const int br = blockIdx.y, cout = p.cout[br];
+  float* tile = psm + wave * 16 * LDW;
+
+  // B operand: W[o][ch], lane (k = 8q + j -> o, column lp -> channel of tile t); rows o >= cout are zero
+  bf16x8_t wf[NT];
+  {
+    const float* w = p.w[br];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = 8 * q + j;
+        wf[t][j] = (__bf16)(o < cout ? w[o * CIN + t * 16 + lp] : 0.f);
+      }
+  }
+  // row layout: this lane owns chunk cc (8 channels) of pixel row (lane / CH) of every pass
+  const int cc = lane % CH, pr = lane / CH;
+  const int c0 = p.xoff[br] + cc * 8;
+  float sc[8], sf[8], mu[8], is[8], m1[8], m2[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = p.scale[c0 + j]; sf[j] = p.shift[c0 + j]; mu[j] = p.mean[c0 + j]; is[j] = p.invstd[c0 + j];
+    if (MODE == 1) { m1[j] = p.mg[c0 + j]; m2[j] = p.mgx[c0 + j]; }
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  const long pbeg = (long)blockIdx.x * p.px_per_block;
+  const long pend = pbeg + p.px_per_block < p.P ? pbeg + p.px_per_block : p.P;
+  const bf16_t* dop = p.dout + p.ooff[br];
+  for (long pb = pbeg; pb < pend; pb += 64) {  // uniform trip count: the barriers below are taken by all four waves
+    const long p0 = pb + wave * 16;
+    // y of this wave's 16 pixels, row layout, issued first (the longest latency)
+    uint4 yv[NPASS];
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s) {
+      const long px = p0 + s * PPP + pr;
+      yv[s] = px < pend ? *(const uint4*)(p.y + px * p.ysw + c0) : make_uint4(0, 0, 0, 0);
+    }
+    // A operand: dout, lane (row lp -> pixel, k = 8q + j -> o)
+    bf16x8_t a;
+    {
+      const long px = p0 + lp;
+      const bool pok = px < pend;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = 8 * q + j;
+        unsigned short raw = 0;
+        if (pok && o < cout) raw = dop[px * p.dsw + o];
+        a[j] = __builtin_bit_cast(__bf16, raw);
+      }
+    }
+    // dz tile -> LDS: D[row = 4q + r -> pixel][column lp -> channel]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[t], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(4 * q + r) * LDW + t * 16 + lp] = d[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s) {
+      const int pl = s * PPP + pr;
+      const long px = p0 + pl;
+      const float4 z0 = *(const float4*)(tile + pl * LDW + cc * 8), z1 = *(const float4*)(tile + pl * LDW + cc * 8 + 4);
+      const float dz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+      float v[8], o[8];
+      Chunk<bf16_t>::unpack(yv[s], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float g = dz[j];
+        if (p.act) g *= silu_grad_f(v[j] * sc[j] + sf[j]);
+        const float xh = (v[j] - mu[j]) * is[j];
+        if (MODE == 0) { s1[j] += g; s2[j] += g * (v[j] - mu[j]) * is[j]; }
+        else o[j] = sc[j] * (g - m1[j] - xh * m2[j]);
+      }
+      if (MODE == 1 && px < pend) *(uint4*)(p.dy + px * p.dysw + c0) = Chunk<bf16_t>::pack(o);
+    }
+    __syncthreads();  // the tile is rewritten by the next step
+  }
+  if (MODE == 0) {
+    // fold the 4 waves x PPP pixel rows that share a chunk; rows past `pend` contributed exact zeros (zero dout rows)
+    float* red = psm;  // [4 * PPP][CIN][2]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[((wave * PPP + pr) * CIN + cc * 8 + j) * 2 + 0] = s1[j];
+      red[((wave * PPP + pr) * CIN + cc * 8 + j) * 2 + 1] = s2[j];
+    }
+    __syncthreads();
+    if (tid < CIN) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int r = 0; r < 4 * PPP; ++r) { a0 += red[(r * CIN + tid) * 2]; a1 += red[(r * CIN + tid) * 2 + 1]; }
+      float* dst = p.part + ((long)blockIdx.x * p.C + p.xoff[br] + tid) * 2;
+      dst[0] = a0;
+      dst[1] = a1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3d_proj_group_bn_bwd_blocks(int64_t P) {
+  long n = (P + 63) / 64;
+  return (int)(n < 1 ? 1 : (n > 128 ? 128 : n));
+}
+
+int y3d_proj_group_bn_bwd(int mode, int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const void* dout, int64_t dsw,
+                          const float* const* w, const int* couts, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* mean_g, const float* mean_gx, int act, float* partials, int nblk, void* dy,
+                          int64_t dysw, int64_t P, int C, void* stream) {
+  Y3D_CHECK(mode == 0 || mode == 1, "proj_group_bn_bwd: mode 0 (reduce) or 1 (apply)");
+  Y3D_CHECK(nb >= 1 && nb <= PB_MAXB && (cin == 64 || cin == 128), "proj_group_bn_bwd: 1..16 branches of 64 or 128 channels");
+  Y3D_CHECK(y_pre && dout && scale && shift && mean && invstd && P >= 1, "proj_group_bn_bwd: null argument");
+  Y3D_CHECK(mode == 0 ? (partials != nullptr && nblk == y3d_proj_group_bn_bwd_blocks(P)) : (dy && mean_g && mean_gx && dysw >= cin),
+            "proj_group_bn_bwd: partials / nblk (reduce) or dy / mean_g / mean_gx (apply) missing");
+  Y3D_CHECK(ysw % 8 == 0 && ((uintptr_t)y_pre & 15) == 0 && (mode == 0 || (dysw % 8 == 0 && ((uintptr_t)dy & 15) == 0)), "proj_group_bn_bwd: 16-byte alignment");
+  PBP p;
+  p.y = (const bf16_t*)y_pre; p.dout = (const bf16_t*)dout; p.dy = (bf16_t*)dy; p.part = partials;
+  int off = 0;
+  for (int i = 0; i < nb; ++i) {
+    Y3D_CHECK(couts[i] >= 1 && couts[i] <= 32 && xoff[i] % 8 == 0 && xoff[i] + cin <= C, "proj_group_bn_bwd: cout in 1..32, channel slices 16-byte aligned inside C");
+    p.w[i] = w[i]; p.xoff[i] = xoff[i]; p.ooff[i] = off; p.cout[i] = couts[i];
+    off += couts[i];
+  }
+  Y3D_CHECK(dsw >= off, "proj_group_bn_bwd: dout pixel stride smaller than the projected channels");
+  p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.mg = mean_g; p.mgx = mean_gx;
+  p.ysw = ysw; p.dsw = dsw; p.dysw = dysw; p.P = P; p.cin = cin; p.C = C; p.act = act;
+  const int nrun = y3d_proj_group_bn_bwd_blocks(P);
+  p.px_per_block = (int)(((P + nrun - 1) / nrun + 63) / 64 * 64);
+  dim3 grid(nrun, nb);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sm128 = (size_t)4 * 16 * (128 + 4) * sizeof(float), sm64 = (size_t)4 * 16 * (64 + 4) * sizeof(float);
+  if (cin == 128) {
+    if (mode == 0) hipLaunchKernelGGL((projg_bn_bwd_kernel<0, 8>), grid, dim3(256), sm128, st, p);
+    else hipLaunchKernelGGL((projg_bn_bwd_kernel<1, 8>), grid, dim3(256), sm128, st, p);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((projg_bn_bwd_kernel<0, 4>), grid, dim3(256), sm64, st, p);
+    else hipLaunchKernelGGL((projg_bn_bwd_kernel<1, 4>), grid, dim3(256), sm64, st, p);
+  }
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+}  // extern "C"

@@ -290,6 +290,7 @@ def set_weight_quant(mode):
 
 def weight_quant():
     return WEIGHT_QUANT
+PROJ_BN_MFMA = not os.environ.get("Y3D_NO_PROJ_BN_MFMA")  # A/B switch: BatchNorm backward of the second head layer recomputing dz on MFMA
 PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv packing launches instead of the registry
 
 
@@ -900,8 +901,6 @@ class FusedConvBNProjFn(torch.autograd.Function):
         tot = sum(couts)
         PV, IA = ctypes.c_void_p * n, ctypes.c_int * n
         c_w, c_off, c_co = PV(*[t.data_ptr() for t in ws]), IA(*offsets), IA(*couts)
-        dz = nhwc_empty(B, Ct, H, W, dtype, dev)
-        L.proj_group_bwd_data(dt, n, cin, dout.data_ptr(), dout.stride(3), c_off, c_w, c_co, dz.data_ptr(), Ct, P, st)
         dws = [torch.empty_like(t) for t in ws]
         dbs = [_f32(co, dev) for co in couts]
         nb = L.proj_group_blocks(P)
@@ -909,7 +908,23 @@ class FusedConvBNProjFn(torch.autograd.Function):
         L.proj_group_bwd_weight_bn(dt, n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, stats[2].data_ptr(),
                                    stats[3].data_ptr(), act, slab.data_ptr(), bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]),
                                    PV(*[t.data_ptr() for t in dbs]), P, st)
-        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None, wver=ctx.wver)
+        if dtype == torch.bfloat16 and cin in (64, 128) and PROJ_BN_MFMA and ctx.cfg[14]:
+            # BatchNorm backward straight from `dout`: dz = dout . W is recomputed on the matrix cores by the reduce and the apply pass
+            # (proj_bn_mfma.hip) instead of being written once and read twice (839 MB at the stride-8 level)
+            nblk = L.proj_group_bn_bwd_blocks(P)
+            part = _f32(nblk * Ct * 2, dev)
+            args = (n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_w, c_co, stats[2].data_ptr(), stats[3].data_ptr(),
+                    stats[0].data_ptr(), stats[1].data_ptr())
+            L.proj_group_bn_bwd(0, *args, None, None, act, part.data_ptr(), nblk, None, 0, P, Ct, st)
+            dgb = _f32(2 * Ct, dev).view(2, Ct)
+            L.bn_bwd_finalize(part.data_ptr(), nblk, Ct, P, dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stats[4].data_ptr(), stats[5].data_ptr(), st)
+            dy = nhwc_empty(B, Ct, H, W, dtype, dev)
+            L.proj_group_bn_bwd(1, *args, stats[4].data_ptr(), stats[5].data_ptr(), act, None, 0, dy.data_ptr(), Ct, P, Ct, st)
+            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, None, ctx.needs_input_grad[0], False, None, pre=(dy, dgb))
+        else:
+            dz = nhwc_empty(B, Ct, H, W, dtype, dev)
+            L.proj_group_bwd_data(dt, n, cin, dout.data_ptr(), dout.stride(3), c_off, c_w, c_co, dz.data_ptr(), Ct, P, st)
+            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None, wver=ctx.wver)
         dWs, dgs, dbs_s, off = [], [], [], 0
         for co in ctx.couts_stack:
             dWs.append(dW[off:off + co])
