@@ -184,6 +184,10 @@ int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t 
  * mode 0: partials [y3d_proj_group_bn_bwd_blocks(P)][C][2] = (sum g, sum g*xhat), g = dz * act'(u)  -> y3d_bn_bwd_finalize;
  * mode 1: dy = scale * (g - mean_g - xhat * mean_gx).  y_pre: the conv's pre-BatchNorm output (C channels, branch i at xoff[i]),
  * dout: gradient of the projected map (branch i's couts[i] channels side by side in branch order). */
+/* the forward of the same stage on the matrix cores (bf16, cin = 64 / 128): out[px][branch i's channels] = W_i . act(y_pre * scale + shift) + b_i */
+int y3d_proj_group_fwd_bn_mfma(int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const float* const* w, const float* const* b,
+                               const int* couts, const float* scale, const float* shift, int act, void* out, int64_t osw, int64_t P,
+                               void* stream);
 int y3d_proj_group_bn_bwd_blocks(int64_t P);
 int y3d_proj_group_bn_bwd(int mode, int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const void* dout, int64_t dsw,
                           const float* const* w, const int* couts, const float* scale, const float* shift, const float* mean,

@@ -511,9 +511,13 @@ def test_proj_bn_mfma_backward_matches_materialised_path(mid, hw, B):
             out = head([xi])
             assert "_y3d_maps" in out
             ((out["one2one"][0].float() * r[0]).sum() + (out["one2many"][0].float() * r[1]).sum()).backward()
-            res[flag] = (xi.grad.float().clone(), {k: v.grad.float().clone() for k, v in head.named_parameters() if v.grad is not None})
+            res[flag] = (xi.grad.float().clone(), {k: v.grad.float().clone() for k, v in head.named_parameters() if v.grad is not None},
+                         out["one2one"][0].float().clone(), out["one2many"][0].float().clone())
         finally:
             ops.PROJ_BN_MFMA = True
+    # forward projections on the matrix cores (bf16 weights) vs the VALU form (fp32 weights): bf16 rounding of 24 x 128 weights
+    check(res[True][2], res[False][2], 2e-2, "one2one map")
+    check(res[True][3], res[False][3], 2e-2, "one2many map")
     check(res[True][0], res[False][0], 2e-2, "dx")
     assert set(res[True][1]) == set(res[False][1])
     big = max(float(v.abs().max()) for v in res[False][1].values())

@@ -136,9 +136,124 @@ __global__ __launch_bounds__(256) void projg_bn_bwd_kernel(PBP p) {
   }
 }
 
+// Forward of the same stage: out[px][ooff + o] = sum_ch act[px][ch] * W[o][ch] + b[o], act = SiLU(BN(y)) formed in the row layout
+// (coalesced 16-byte loads, lane-stationary scale / shift), handed to the matrix cores through a per-wave bf16 LDS tile:
+// K = cin (2-4 MFMA k-steps), N = cout padded to 16 / 32.  The VALU form (proj_group.hip: projg_fwd_kernel) spent 24 x cin
+// multiply-adds per pixel and branch on outputs that mostly do not exist (cout = 1..3 for 12 of the 16 branches): 0.57 ms at P3.
+struct PFP {
+  const bf16_t* y;
+  bf16_t* out;
+  const float* w[PB_MAXB];
+  const float* b[PB_MAXB];
+  int xoff[PB_MAXB], ooff[PB_MAXB], cout[PB_MAXB];
+  const float *scale, *shift;
+  long ysw, osw, P;
+  int act, px_per_block;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void projg_fwd_bn_mfma_kernel(PFP p) {
+  constexpr int CIN = NT * 16, KS = CIN / 32;
+  constexpr int LDB = CIN * 2 + 16;  // LDS row pitch in BYTES (bf16 rows + one 16-byte slot: rows land on different bank groups)
+  constexpr int CH = CIN / 8, PPP = 64 / CH, NPASS = 16 / PPP;
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, lp = lane & 15;
+  const int br = blockIdx.y, cout = p.cout[br];
+  char* tile = (char*)psm + wave * 16 * LDB;
+  // B operand: W^T, lane (k = 8q + j -> channel 32 ks + 8q + j, column lp -> output 16 n + lp)
+  bf16x8_t wf[2][KS];
+  float bias[2];
+  {
+    const float* w = p.w[br];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int o = 16 * n + lp;
+      bias[n] = o < cout ? p.b[br][o] : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[n][ks][j] = (__bf16)(o < cout ? w[o * CIN + ks * 32 + 8 * q + j] : 0.f);
+    }
+  }
+  const int cc = lane % CH, pr = lane / CH;
+  const int c0 = p.xoff[br] + cc * 8;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = p.scale[c0 + j]; sf[j] = p.shift[c0 + j]; }
+  const long pbeg = (long)blockIdx.x * p.px_per_block;
+  const long pend = pbeg + p.px_per_block < p.P ? pbeg + p.px_per_block : p.P;
+  bf16_t* op = p.out + p.ooff[br];
+  const bool two = cout > 16;  // uniform per workgroup
+  for (long pb = pbeg; pb < pend; pb += 64) {
+    const long p0 = pb + wave * 16;
+    uint4 yv[NPASS];
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s) {
+      const long px = p0 + s * PPP + pr;
+      yv[s] = px < pend ? *(const uint4*)(p.y + px * p.ysw + c0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s) {
+      float v[8];
+      Chunk<bf16_t>::unpack(yv[s], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = v[j] * sc[j] + sf[j];
+        v[j] = p.act ? silu_f(u) : u;
+      }
+      *(uint4*)(tile + (s * PPP + pr) * LDB + cc * 16) = Chunk<bf16_t>::pack(v);  // rounded as the materialised activation would be
+    }
+    __syncthreads();
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)(tile + lp * LDB + (ks * 4 + q) * 16));
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[0][ks], acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[1][ks], acc1, 0, 0, 0);
+    }
+    // D[row = 4q + r -> pixel][column lp -> output]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long px = p0 + 4 * q + r;
+      if (px < pend) {
+        if (lp < cout) op[px * p.osw + lp] = f2bf(acc0[r] + bias[0]);
+        if (two && 16 + lp < cout) op[px * p.osw + 16 + lp] = f2bf(acc1[r] + bias[1]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int y3d_proj_group_fwd_bn_mfma(int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const float* const* w, const float* const* b,
+                               const int* couts, const float* scale, const float* shift, int act, void* out, int64_t osw, int64_t P,
+                               void* stream) {
+  Y3D_CHECK(nb >= 1 && nb <= PB_MAXB && (cin == 64 || cin == 128), "proj_group_fwd_bn_mfma: 1..16 branches of 64 or 128 channels");
+  Y3D_CHECK(y_pre && out && scale && shift && P >= 1 && ysw % 8 == 0 && ((uintptr_t)y_pre & 15) == 0, "proj_group_fwd_bn_mfma: null / misaligned argument");
+  PFP p;
+  p.y = (const bf16_t*)y_pre; p.out = (bf16_t*)out;
+  int off = 0;
+  for (int i = 0; i < nb; ++i) {
+    Y3D_CHECK(couts[i] >= 1 && couts[i] <= 32 && xoff[i] % 8 == 0, "proj_group_fwd_bn_mfma: cout in 1..32, channel slices 16-byte aligned");
+    p.w[i] = w[i]; p.b[i] = b[i]; p.xoff[i] = xoff[i]; p.ooff[i] = off; p.cout[i] = couts[i];
+    off += couts[i];
+  }
+  Y3D_CHECK(osw >= off, "proj_group_fwd_bn_mfma: output pixel stride smaller than the projected channels");
+  p.scale = scale; p.shift = shift; p.ysw = ysw; p.osw = osw; p.P = P; p.act = act;
+  long nrun = (P + 63) / 64;
+  if (nrun > 128) nrun = 128;
+  p.px_per_block = (int)(((P + nrun - 1) / nrun + 63) / 64 * 64);
+  dim3 grid((unsigned)nrun, nb);
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 128) hipLaunchKernelGGL((projg_fwd_bn_mfma_kernel<8>), grid, dim3(256), (size_t)4 * 16 * (128 * 2 + 16), st, p);
+  else hipLaunchKernelGGL((projg_fwd_bn_mfma_kernel<4>), grid, dim3(256), (size_t)4 * 16 * (64 * 2 + 16), st, p);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
 
 int y3d_proj_group_bn_bwd_blocks(int64_t P) {
   long n = (P + 63) / 64;

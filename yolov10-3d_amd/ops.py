@@ -875,8 +875,12 @@ class FusedConvBNProjFn(torch.autograd.Function):
         b32 = [t.detach().float().contiguous() for t in bs]
         PV, IA = ctypes.c_void_p * n, ctypes.c_int * n
         stats = saved[3]
-        L.proj_group_fwd_bn(dt, n, cin, y.data_ptr(), y.stride(3), IA(*offsets), PV(*[t.data_ptr() for t in w32]), PV(*[t.data_ptr() for t in b32]),
-                            IA(*couts), stats[2].data_ptr(), stats[3].data_ptr(), int(m.has_act), out.data_ptr(), tot, P, st)
+        if dtype == torch.bfloat16 and cin in (64, 128) and PROJ_BN_MFMA:
+            L.proj_group_fwd_bn_mfma(n, cin, y.data_ptr(), y.stride(3), IA(*offsets), PV(*[t.data_ptr() for t in w32]), PV(*[t.data_ptr() for t in b32]),
+                                     IA(*couts), stats[2].data_ptr(), stats[3].data_ptr(), int(m.has_act), out.data_ptr(), tot, P, st)
+        else:
+            L.proj_group_fwd_bn(dt, n, cin, y.data_ptr(), y.stride(3), IA(*offsets), PV(*[t.data_ptr() for t in w32]), PV(*[t.data_ptr() for t in b32]),
+                                IA(*couts), stats[2].data_ptr(), stats[3].data_ptr(), int(m.has_act), out.data_ptr(), tot, P, st)
         ctx.cfg, ctx.couts_stack, ctx.meta = cfg, stack.couts, (list(offsets), cin, n, couts, dtype, int(m.has_act))
         ctx.nsaved = len(saved)
         ctx.save_for_backward(*[t for t in saved if t is not None], *w32)
