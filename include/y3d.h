@@ -188,6 +188,12 @@ int y3d_proj_group_bwd_data(int dtype, int nb, int cin, const void* dy, int64_t 
 int y3d_proj_group_fwd_bn_mfma(int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const float* const* w, const float* const* b,
                                const int* couts, const float* scale, const float* shift, int act, void* out, int64_t osw, int64_t P,
                                void* stream);
+/* ... and its weight / bias gradients (contraction over pixels; transposed LDS reads): slab = blocks * sum(couts) * cin floats,
+ * bslab = blocks * sum(couts) floats, blocks = y3d_proj_group_bwd_weight_bn_mfma_blocks(P) */
+int y3d_proj_group_bwd_weight_bn_mfma_blocks(int64_t P);
+int y3d_proj_group_bwd_weight_bn_mfma(int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const void* dout, int64_t dsw,
+                                      const int* couts, const float* scale, const float* shift, int act, float* slab, float* bslab,
+                                      float* const* dw, float* const* db, int64_t P, void* stream);
 int y3d_proj_group_bn_bwd_blocks(int64_t P);
 int y3d_proj_group_bn_bwd(int mode, int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const void* dout, int64_t dsw,
                           const float* const* w, const int* couts, const float* scale, const float* shift, const float* mean,

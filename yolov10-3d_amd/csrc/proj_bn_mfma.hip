@@ -225,9 +225,179 @@ __global__ __launch_bounds__(256) void projg_fwd_bn_mfma_kernel(PFP p) {
   }
 }
 
+// Weight / bias gradient of the projections: dW[o][ch] = sum_px dout[px][o] * act[px][ch], db[o] = sum_px dout[px][o] - a contraction
+// over PIXELS.  Per wave and step of 32 pixels: act = SiLU(BN(y)) is formed in the row layout and parked in a bf16 LDS tile; the B
+// operand (k = pixel, column = channel) is read back with the transposed LDS read (ds_read_tr16_b64: two 4 x 16 blocks per
+// fragment), the A operand is dout^T (row = output, k = pixel: eight 2-byte loads per lane, only the cout <= 24 live rows load).
+// Both use the same pixel <-> k permutation: k = 8g + j  <->  row 16 (j >> 2) + 4g + (j & 3) of the step.
+struct PWP {
+  const bf16_t* y;
+  const bf16_t* dout;
+  float* slab;   // [gridDim.x][ctot][cin]
+  float* bslab;  // [gridDim.x][ctot]
+  float* dw[PB_MAXB];
+  float* db[PB_MAXB];
+  int xoff[PB_MAXB], ooff[PB_MAXB], cout[PB_MAXB];
+  const float *scale, *shift;
+  long ysw, dsw, P;
+  int act, px_per_block, ctot;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void projg_bwd_weight_bn_mfma_kernel(PWP p) {
+  constexpr int CIN = NT * 16;
+  constexpr int LDB = CIN * 2 + 32;  // tile row pitch in bytes (8 x odd dwords: the 8 rows of a transposed read cover all banks once)
+  constexpr int CH = CIN / 8, PPP = 64 / CH, NPASS = 32 / PPP;
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lp = lane & 15;
+  const int br = blockIdx.y, cout = p.cout[br];
+  const bool two = cout > 16;  // uniform
+  char* tile = (char*)psm + wave * 32 * LDB;
+  const int cc = lane % CH, pr = lane / CH;
+  const int c0 = p.xoff[br] + cc * 8;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = p.scale[c0 + j]; sf[j] = p.shift[c0 + j]; }
+  f32x4_t acc[2][NT];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[n][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const long pbeg = (long)blockIdx.x * p.px_per_block;
+  const long pend = pbeg + p.px_per_block < p.P ? pbeg + p.px_per_block : p.P;
+  const bf16_t* dop = p.dout + p.ooff[br];
+  // transposed-read address of this lane inside a 4-row block: lane 4q' + p' of a 16-lane group supplies row q', columns 4p' .. 4p'+3
+  const int trow = 4 * g + (lp >> 2), tcol = (lp & 3) * 4;
+  for (long pb = pbeg; pb < pend; pb += 128) {
+    const long p0 = pb + wave * 32;
+    uint4 yv[NPASS];
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s) {
+      const long px = p0 + s * PPP + pr;
+      yv[s] = px < pend ? *(const uint4*)(p.y + px * p.ysw + c0) : make_uint4(0, 0, 0, 0);
+    }
+    // A operands: dout^T rows 0..15 (and 16..31 for the 24-output branch)
+    bf16x8_t a[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long px = p0 + 16 * (j >> 2) + 4 * g + (j & 3);
+        const int o = 16 * n + lp;
+        unsigned short raw = 0;
+        if ((n == 0 || two) && o < cout && px < pend) raw = dop[px * p.dsw + o];
+        a[n][j] = __builtin_bit_cast(__bf16, raw);
+        bsum[n] += bf2f(raw);
+      }
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s) {
+      float v[8];
+      Chunk<bf16_t>::unpack(yv[s], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = v[j] * sc[j] + sf[j];
+        v[j] = p.act ? silu_f(u) : u;
+      }
+      // pixels past the end hold act(shift) != 0, but their dout rows are zero: they add nothing
+      *(uint4*)(tile + (s * PPP + pr) * LDB + cc * 16) = Chunk<bf16_t>::pack(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const char* a0 = tile + trow * LDB + (t * 16 + tcol) * 2;
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 16 * LDB));
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      const bf16x8_t b = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b, acc[0][t], 0, 0, 0);
+      if (two) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b, acc[1][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // fold the four waves: red[wave][o 0..31][CIN]; D[row = 4g + r -> output][column lp -> channel of tile t]
+  float* red = psm;
+  const int NO = two ? 2 : 1;
+  for (int n = 0; n < NO; ++n)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * n + 4 * g + r) * CIN + t * 16 + lp] = (n == 0 ? acc[0][t][r] : acc[1][t][r]);
+  // bias sums: lanes (lp = o, g) -> fold the four k groups of the wave, then the waves
+  __shared__ float bred[4][32];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    float v = bsum[n];
+    v = lane_xor32_sum(lane_xor16_sum(v));
+    if (g == 0) bred[wave][16 * n + lp] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < cout * CIN; i += 256) {
+    const int o = i / CIN, ch = i - o * CIN;
+    p.slab[((long)blockIdx.x * p.ctot + p.ooff[br] + o) * CIN + ch] =
+        red[(0 * 32 + o) * CIN + ch] + red[(1 * 32 + o) * CIN + ch] + red[(2 * 32 + o) * CIN + ch] + red[(3 * 32 + o) * CIN + ch];
+  }
+  if (tid < cout) p.bslab[(long)blockIdx.x * p.ctot + p.ooff[br] + tid] = bred[0][tid] + bred[1][tid] + bred[2][tid] + bred[3][tid];
+}
+
+// dw[br][o][ch] = sum_blk slab[blk][ooff + o][ch];  db[br][o] = sum_blk bslab[blk][ooff + o]
+__global__ void projg_wslab_reduce_kernel(PWP p, int nblk, int cin) {
+  const int br = blockIdx.y, cout = p.cout[br];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < cout * cin) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += p.slab[((long)b * p.ctot + p.ooff[br]) * cin + idx];
+    p.dw[br][idx] = s;
+  }
+  if (idx < cout) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += p.bslab[(long)b * p.ctot + p.ooff[br] + idx];
+    p.db[br][idx] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int y3d_proj_group_bwd_weight_bn_mfma_blocks(int64_t P) {
+  long n = (P + 1023) / 1024;
+  return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+}
+
+int y3d_proj_group_bwd_weight_bn_mfma(int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const void* dout, int64_t dsw,
+                                      const int* couts, const float* scale, const float* shift, int act, float* slab, float* bslab,
+                                      float* const* dw, float* const* db, int64_t P, void* stream) {
+  Y3D_CHECK(nb >= 1 && nb <= PB_MAXB && (cin == 64 || cin == 128), "proj_group_bwd_weight_bn_mfma: 1..16 branches of 64 or 128 channels");
+  Y3D_CHECK(y_pre && dout && scale && shift && slab && bslab && dw && db && P >= 1 && ysw % 8 == 0 && ((uintptr_t)y_pre & 15) == 0,
+            "proj_group_bwd_weight_bn_mfma: null / misaligned argument");
+  PWP p;
+  p.y = (const bf16_t*)y_pre; p.dout = (const bf16_t*)dout; p.slab = slab; p.bslab = bslab;
+  int off = 0;
+  for (int i = 0; i < nb; ++i) {
+    Y3D_CHECK(couts[i] >= 1 && couts[i] <= 32 && xoff[i] % 8 == 0, "proj_group_bwd_weight_bn_mfma: cout in 1..32, channel slices 16-byte aligned");
+    p.dw[i] = dw[i]; p.db[i] = db[i]; p.xoff[i] = xoff[i]; p.ooff[i] = off; p.cout[i] = couts[i];
+    off += couts[i];
+  }
+  Y3D_CHECK(dsw >= off, "proj_group_bwd_weight_bn_mfma: dout pixel stride smaller than the projected channels");
+  p.scale = scale; p.shift = shift; p.ysw = ysw; p.dsw = dsw; p.P = P; p.act = act; p.ctot = off;
+  const int nrun = y3d_proj_group_bwd_weight_bn_mfma_blocks(P);
+  p.px_per_block = (int)(((P + nrun - 1) / nrun + 127) / 128 * 128);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sm = (size_t)4 * 32 * cin * sizeof(float);  // the cross-wave fold (>= the four bf16 tiles)
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)projg_bwd_weight_bn_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 128 * 4);
+    (void)hipFuncSetAttribute((const void*)projg_bwd_weight_bn_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 64 * 4);
+    attr = true;
+  }
+  if (cin == 128) hipLaunchKernelGGL((projg_bwd_weight_bn_mfma_kernel<8>), dim3(nrun, nb), dim3(256), sm, st, p);
+  else hipLaunchKernelGGL((projg_bwd_weight_bn_mfma_kernel<4>), dim3(nrun, nb), dim3(256), sm, st, p);
+  hipLaunchKernelGGL(projg_wslab_reduce_kernel, dim3((32 * cin + 255) / 256, nb), dim3(256), 0, st, p, nrun, cin);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
 
 int y3d_proj_group_fwd_bn_mfma(int nb, int cin, const void* y_pre, int64_t ysw, const int* xoff, const float* const* w, const float* const* b,
                                const int* couts, const float* scale, const float* shift, int act, void* out, int64_t osw, int64_t P,

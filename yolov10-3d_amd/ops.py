@@ -907,12 +907,18 @@ class FusedConvBNProjFn(torch.autograd.Function):
         c_w, c_off, c_co = PV(*[t.data_ptr() for t in ws]), IA(*offsets), IA(*couts)
         dws = [torch.empty_like(t) for t in ws]
         dbs = [_f32(co, dev) for co in couts]
-        nb = L.proj_group_blocks(P)
+        mfma = dtype == torch.bfloat16 and cin in (64, 128) and PROJ_BN_MFMA
+        nb = L.proj_group_bwd_weight_bn_mfma_blocks(P) if mfma else L.proj_group_blocks(P)
         slab, bslab = _f32(nb * tot * cin, dev), _f32(nb * tot, dev)
-        L.proj_group_bwd_weight_bn(dt, n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, stats[2].data_ptr(),
-                                   stats[3].data_ptr(), act, slab.data_ptr(), bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]),
-                                   PV(*[t.data_ptr() for t in dbs]), P, st)
-        if dtype == torch.bfloat16 and cin in (64, 128) and PROJ_BN_MFMA and ctx.cfg[14]:
+        if mfma:
+            L.proj_group_bwd_weight_bn_mfma(n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, stats[2].data_ptr(),
+                                            stats[3].data_ptr(), act, slab.data_ptr(), bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]),
+                                            PV(*[t.data_ptr() for t in dbs]), P, st)
+        else:
+            L.proj_group_bwd_weight_bn(dt, n, cin, y.data_ptr(), y.stride(3), c_off, dout.data_ptr(), dout.stride(3), c_co, stats[2].data_ptr(),
+                                       stats[3].data_ptr(), act, slab.data_ptr(), bslab.data_ptr(), PV(*[t.data_ptr() for t in dws]),
+                                       PV(*[t.data_ptr() for t in dbs]), P, st)
+        if mfma and ctx.cfg[14]:
             # BatchNorm backward straight from `dout`: dz = dout . W is recomputed on the matrix cores by the reduce and the apply pass
             # (proj_bn_mfma.hip) instead of being written once and read twice (839 MB at the stride-8 level)
             nblk = L.proj_group_bn_bwd_blocks(P)
