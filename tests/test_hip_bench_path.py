@@ -523,3 +523,98 @@ def test_proj_bn_mfma_backward_matches_materialised_path(mid, hw, B):
     big = max(float(v.abs().max()) for v in res[False][1].values())
     for k, v in res[False][1].items():
         check(res[True][1][k], v, 3e-2, f"grad {k}", floor=1e-3 * big)
+
+
+# ---- streaming 1x1 kernel (conv1x1_stream.hip) ---------------------------------------------------------------------------------
+def _conv1x1_abi(x, w, dy, bias=None, affine=None, stream=True):
+    """bf16 1x1 conv forward (+ BN partial sums, or bias, or folded affine + SiLU) and data gradient through the C ABI.
+    x: (B, Ctot, H, W) NHWC device tensor whose channel slice [lo, lo + Cin) is the input (a channel-slice VIEW, as C2f feeds its cv2)"""
+    L, st, dt = y3d.lib(), ops.stream(), BF16
+    (xt, lo, Cin), Cout = x, w.shape[0]
+    B, _, H, W = xt.shape
+    bf = torch.bfloat16
+    xin = xt[:, lo:lo + Cin]
+    sb, sh, sw = ops.s3(xin)
+    wd = w.to(DEV).contiguous()
+    wp = torch.empty(Cout * Cin, dtype=bf, device=DEV)
+    L.pack_weight_fwd(dt, wd.data_ptr(), wp.data_ptr(), Cout, Cin, Cin, 1, 1, st)
+    nblk = L.conv2d_stat_rows(dt, B, H, W, Cin, Cout, 1, 1, 1, 1, 0)
+    part = torch.full((nblk, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+    y = ops.nhwc_empty(B, Cout, H, W, bf, DEV)
+    old = L.set_stream1x1(1 if stream else 0)
+    try:
+        if affine is not None:
+            sc, sf = (t.to(DEV).contiguous() for t in affine)
+            L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), sc.data_ptr(), sf.data_ptr(), 1, y.data_ptr(), Cout, H, W,
+                                Cout, 1, 1, 1, 1, 0, st)
+        else:
+            bd = bias.to(DEV).contiguous() if bias is not None else None
+            L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), bd.data_ptr() if bd is not None else None, y.data_ptr(), Cout, H, W,
+                         Cout, 1, 1, 1, 1, 0, None if bd is not None else part.data_ptr(), st)
+        kp = L.conv_kpad(dt, Cout)
+        wpd = torch.empty(Cin * kp, dtype=bf, device=DEV)
+        L.pack_weight_dgrad(dt, wd.data_ptr(), wpd.data_ptr(), Cout, Cin, 1, 1, 1, st)
+        dx = torch.zeros_like(xt)
+        dxv = dx[:, lo:lo + Cin]
+        dsb, dsh, dsw = ops.s3(dy)
+        L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, H, W, Cout, wpd.data_ptr(), dxv.data_ptr(), dxv.stride(3), H, W, Cin, 1, 1, 1, 1, 0, st)
+        torch.cuda.synchronize()
+    finally:
+        L.set_stream1x1(old)
+    return y, part, dx
+
+
+STREAM_SHAPES = [
+    # B, H, W, Ctot, lo, Cin, Cout
+    (2, 40, 40, 64, 0, 64, 64),        # one K chunk, BN = 64
+    (3, 17, 23, 192, 64, 96, 128),     # ragged pixel count, channel-slice view, K = 96 (half-filled last chunk), BN = 128
+    (2, 24, 24, 32, 0, 32, 32),        # K = 32: one MFMA step per stage
+    (1, 33, 31, 384, 0, 384, 136),     # N = 136: two channel tiles, the second nearly empty
+    (2, 20, 20, 256, 0, 256, 256),     # BN = 128 x 2 tiles (the weights of a 256-wide tile do not leave room for the ring)
+    (5, 16, 16, 128, 0, 128, 256),     # BN = 256
+]
+
+
+@pytest.mark.parametrize("shape", STREAM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_stream1x1_matches_generic_kernel_and_exact_integer_conv(shape):
+    """The streaming kernel accumulates in the generic kernel's K order: y and dx must be BIT-IDENTICAL to it, and on small-integer
+    operands (fp32 accumulation exact, bf16 stores exact) equal to fp32 conv2d on the host; the BatchNorm partial sums are exact
+    integers there too, whatever the grouping into rows."""
+    B, H, W, Ctot, lo, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    xf = _sparse_int((B, Ctot, H, W), g, 0.25)
+    wf = _sparse_int((Cout, Cin, 1, 1), g, 0.25)
+    dyf = _sparse_int((B, Cout, H, W), g, 0.25)
+    xt = ops.nhwc_empty(B, Ctot, H, W, torch.bfloat16, DEV)
+    xt.copy_(xf.to(DEV))
+    dy = ops.nhwc_empty(B, Cout, H, W, torch.bfloat16, DEV)
+    dy.copy_(dyf.to(DEV))
+    L = y3d.lib()
+    assert L.set_stream1x1(1) in (0, 1)
+    y1, p1, dx1 = _conv1x1_abi((xt, lo, Cin), wf, dy, stream=True)
+    y0, p0, dx0 = _conv1x1_abi((xt, lo, Cin), wf, dy, stream=False)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    yr = torch.nn.functional.conv2d(xf[:, lo:lo + Cin], wf)
+    assert torch.equal(y1.float().cpu(), yr)
+    dxr = torch.nn.functional.conv_transpose2d(dyf, wf)
+    assert torch.equal(dx1[:, lo:lo + Cin].float().cpu(), dxr)
+    assert float(dx1[:, :lo].abs().sum()) == 0 and float(dx1[:, lo + Cin:].abs().sum()) == 0  # the view's neighbours are untouched
+    assert not torch.isnan(p1).any()
+    ref = torch.stack([yr.sum((0, 2, 3)), (yr * yr).sum((0, 2, 3))], 1).double()
+    assert torch.equal(p1.double().sum(0).cpu(), ref) and torch.equal(p0.double().sum(0).cpu(), ref)
+
+
+def test_stream1x1_bias_and_affine_epilogues_match_generic_kernel():
+    B, H, W, Cin, Cout = 2, 19, 21, 128, 72
+    g = torch.Generator().manual_seed(5)
+    xt = ops.nhwc_empty(B, Cin, H, W, torch.bfloat16, DEV)
+    xt.copy_(torch.randn(B, Cin, H, W, generator=g).to(DEV))
+    dy = ops.nhwc_empty(B, Cout, H, W, torch.bfloat16, DEV)
+    dy.copy_(torch.randn(B, Cout, H, W, generator=g).to(DEV))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    aff = (1 + 0.1 * torch.randn(Cout, generator=g), torch.randn(Cout, generator=g))
+    for kw in ({"bias": bias}, {"affine": aff}):
+        y1, _, dx1 = _conv1x1_abi((xt, 0, Cin), w, dy, stream=True, **kw)
+        y0, _, dx0 = _conv1x1_abi((xt, 0, Cin), w, dy, stream=False, **kw)
+        assert torch.equal(y1, y0) and torch.equal(dx1, dx0), list(kw)

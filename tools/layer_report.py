@@ -45,5 +45,5 @@ for key, ts in res.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"{name} {S}x{S} B={B}: conv launches {tot:.2f} ms/step (timed with events, includes launch gaps)")
-for ms, kind, shp, n, tf in rows[:45]:
+for ms, kind, shp, n, tf in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 400]:
     print(f"{ms:7.3f} ms/step  {kind:10s} HxW={shp[0]:3d}x{shp[1]:<3d} {shp[2]:5d}->{shp[3]:<5d} k{shp[4]} s{shp[5]} g{shp[6]:<3d} n={n:4.1f}  {tf:7.1f} TFLOP/s")

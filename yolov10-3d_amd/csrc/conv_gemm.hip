@@ -654,6 +654,14 @@ int y3d_wgrad_tile_splits(int th, int B, int H, int W, int Cg, int Cn, int G);
 int y3d_conv3x3_wgrad_tile_launch(int th, const void* x, long xsb, long xsh, long xsw, const void* dy, long dsw, int B, int H, int W, int Cg,
                                   int Cn, int G, float* slab, int nsplit, void* stream);
 
+// conv1x1_stream.hip
+int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw);
+int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, const float* bias, const float* scale, const float* shift, int act,
+                              void* y, long ysw, float* part, long M, int K, int N, void* stream);
+static inline bool dense_pixels(int B, int H, int W, long sb, long sh, long sw) {
+  return (H == 1 || sh == (long)W * sw) && (B == 1 || sb == (long)H * W * sw);
+}
+
 static int g_tile_kernels = 1;
 extern "C" int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_g, int groups, int kh, int kw);
 
@@ -744,6 +752,9 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
   p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, H, W, xsb, xsh, xsw) &&
+      y3d_conv1x1_stream_ok(dtype, p.M, Cin, Cout, xsw))
+    return y3d_conv1x1_stream_launch(x, xsw, w_packed, p.Kpad, bias, scale, shift, act, y, ysw, stat_partials, p.M, Cin, Cout, stream);
   if (!bias && g_tile_kernels) {
     int th = y3d_tile_height(dtype, B, H, W, p.Cg, p.Cn, groups, kh, kw, stride, pad);
     if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, scale, shift, act, stream);
@@ -785,6 +796,9 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   p.Cg = Cout / groups; p.Cn = Cin / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = y3d_conv_kpad(dtype, p.Ktot); p.M = B * H * W;
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
+      y3d_conv1x1_stream_ok(dtype, p.M, Cout, Cin, dsw))
+    return y3d_conv1x1_stream_launch(dy, dsw, w_packed_dgrad, p.Kpad, nullptr, nullptr, nullptr, 0, dx, xsw, nullptr, p.M, Cout, Cin, stream);
   if (g_tile_kernels) {
     // a 3x3 s1 p1 data gradient is the same conv on dy with flipped taps (Ho == H, Wo == W)
     int th = y3d_tile_height(dtype, B, Ho, Wo, p.Cg, p.Cn, groups, kh, kw, stride, pad);
