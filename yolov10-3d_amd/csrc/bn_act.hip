@@ -79,10 +79,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
                                   int C, int px_per_block) {
   // channel-stationary: a block owns a 64-channel slab and a run of pixels, scale/shift live in registers, two pixels in flight
   constexpr int CE = TT<T>::CE;
-  constexpr int CT = 64 / CE, PT = 256 / CT;
+  // a slab narrower than 64 channels (C = 32, or the last slab of C = 96) spends its spare chunk-threads on more pixels: with a
+  // fixed 8 chunk-threads the 32-channel tensors of the first two stages ran with half of every wave idle (2.8-3.8 TB/s)
+  const int left = (C - (int)blockIdx.y * 64) / CE;
+  const int CT = left < 64 / CE ? left : 64 / CE, PT = 256 / CT;
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
   const int c = blockIdx.y * 64 + ct * CE;
-  if (c >= C) return;
+  if (pt >= PT) return;
   float sc[CE], sf[CE];
 #pragma unroll
   for (int j = 0; j < CE; ++j) { sc[j] = scale[c + j]; sf[j] = shift[c + j]; }
@@ -125,15 +128,16 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, cons
                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                          const float* __restrict__ invstd, float* __restrict__ part, long P, int C, int px_per_block) {
   constexpr int CE = TT<T>::CE;
-  constexpr int CT = 64 / CE;    // chunk-threads per 64-channel slab
-  constexpr int PT = 256 / CT;   // pixel-threads
-  __shared__ float sh[PT][64][2];
+  // chunk-threads per slab: 64 / CE, fewer when the slab is narrower (see bn_act_fwd_kernel); the rest are pixel-threads
+  const int left = (C - (int)blockIdx.y * 64) / CE;
+  const int CT = left < 64 / CE ? left : 64 / CE, PT = 256 / CT, SW = CT * CE;
+  __shared__ float sh[256 / (64 / CE) * 64 * 2];  // [PT][SW][2]: PT * SW <= 256 * CE
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
   const int c = blockIdx.y * 64 + ct * CE;
   float s1[CE], s2[CE];
 #pragma unroll
   for (int j = 0; j < CE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (c < C) {
+  if (pt < PT) {
     float sc[CE], sf[CE], mu[CE], is[CE];
 #pragma unroll
     for (int j = 0; j < CE; ++j) { sc[j] = scale[c + j]; sf[j] = shift[c + j]; mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
@@ -171,14 +175,16 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, cons
       one(*(const uint4*)(y + px * ysw + c), *(const uint4*)(dz + px * dsw + c), r0);
     }
   }
+  if (pt < PT) {
 #pragma unroll
-  for (int j = 0; j < CE; ++j) { sh[pt][ct * CE + j][0] = s1[j]; sh[pt][ct * CE + j][1] = s2[j]; }
+    for (int j = 0; j < CE; ++j) { sh[(pt * SW + ct * CE + j) * 2] = s1[j]; sh[(pt * SW + ct * CE + j) * 2 + 1] = s2[j]; }
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < SW) {
     int cc = blockIdx.y * 64 + threadIdx.x;
     if (cc < C) {
       float a = 0.f, b = 0.f;
-      for (int r = 0; r < PT; ++r) { a += sh[r][threadIdx.x][0]; b += sh[r][threadIdx.x][1]; }
+      for (int r = 0; r < PT; ++r) { a += sh[(r * SW + threadIdx.x) * 2]; b += sh[(r * SW + threadIdx.x) * 2 + 1]; }
       part[((long)blockIdx.x * C + cc) * 2] = a;
       part[((long)blockIdx.x * C + cc) * 2 + 1] = b;
     }
@@ -224,11 +230,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                         const float* __restrict__ mgx, T* __restrict__ dy, long dysw, T* __restrict__ dres,
                                         long drsw, long P, int C, int px_per_block) {
   constexpr int CE = TT<T>::CE;
-  constexpr int CT = 64 / CE;    // chunk-threads per 64-channel slab
-  constexpr int PT = 256 / CT;   // pixel-threads
+  const int left = (C - (int)blockIdx.y * 64) / CE;
+  const int CT = left < 64 / CE ? left : 64 / CE, PT = 256 / CT;  // chunk-threads per slab, pixel-threads (see bn_act_fwd_kernel)
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
   const int c = blockIdx.y * 64 + ct * CE;
-  if (c >= C) return;
+  if (pt >= PT) return;
   // dy = a * g + b * y + k   with  a = scale, b = -scale * invstd^2... kept explicit for exactness with the reference formula
   float sc[CE], sf[CE], mu[CE], is[CE], m1[CE], m2[CE];
 #pragma unroll
