@@ -618,3 +618,46 @@ def test_stream1x1_bias_and_affine_epilogues_match_generic_kernel():
         y1, _, dx1 = _conv1x1_abi((xt, 0, Cin), w, dy, stream=True, **kw)
         y0, _, dx0 = _conv1x1_abi((xt, 0, Cin), w, dy, stream=False, **kw)
         assert torch.equal(y1, y0) and torch.equal(dx1, dx0), list(kw)
+
+
+def test_mt_pack_weights_matches_single_tensor_packing():
+    """The per-step multi-tensor pack (LDS-staged transposes) against the per-conv packing kernels, both layouts, on the geometries
+    the models use: 3x3 / 1x1 / 7x7, grouped, a padded stem (Cg_pad > Cg), a K that needs row padding, chunk boundaries inside rows."""
+    L, st = y3d.lib(), ops.stream()
+    g = torch.Generator().manual_seed(11)
+    geos = [(128, 128, 1, 3), (2048, 128, 1, 3), (2048, 128, 16, 3), (64, 32, 1, 1), (256, 384, 1, 1), (36, 64, 1, 1), (32, 3, 1, 3), (96, 96, 1, 3),
+            (64, 64, 1, 7), (24, 128, 1, 1)]
+    for mode in (0, 1):
+        ents, descs, ct, co = [], [], [], []
+        CH = 16384
+        for t, (Cout, Cin, G, k) in enumerate(geos):
+            Cg, taps = Cin // G, k * k
+            if mode == 1 and Cg % 8:
+                continue
+            w = torch.randn(Cout, Cg, k, k, generator=g).to(DEV)
+            if mode == 0:
+                Cgp = (Cg + 7) // 8 * 8
+                kpad = taps * Cgp
+                n, geo = Cout * kpad, (Cout, Cg, Cgp, taps, kpad)
+                ref = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+                L.pack_weight_fwd(BF16, w.data_ptr(), ref.data_ptr(), Cout, Cg, Cgp, k, k, st)
+            else:
+                Cn = Cout // G
+                kpad = L.conv_kpad(BF16, taps * Cn)
+                n, geo = G * Cg * kpad, (G, Cn, Cg, taps, kpad)
+                ref = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+                L.pack_weight_dgrad(BF16, w.data_ptr(), ref.data_ptr(), Cout, Cg, G, k, k, st)
+            dst = torch.full((n,), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ti = len(ents)
+            ents.append((w, ref, dst))
+            descs += [w.data_ptr(), dst.data_ptr(), *geo, mode]
+            for j in range((n + CH - 1) // CH):
+                ct.append(ti)
+                co.append(j)
+        t_desc = torch.tensor(descs, dtype=torch.int64, device=DEV)
+        t_ct = torch.tensor(ct, dtype=torch.int32, device=DEV)
+        t_co = torch.tensor(co, dtype=torch.int32, device=DEV)
+        L.mt_pack_weights(BF16, t_desc.data_ptr(), t_ct.data_ptr(), t_co.data_ptr(), len(ct), CH, st)
+        torch.cuda.synchronize()
+        for i, (w, ref, dst) in enumerate(ents):
+            assert torch.equal(dst.view(torch.int16), ref.view(torch.int16)), (mode, i, tuple(w.shape))

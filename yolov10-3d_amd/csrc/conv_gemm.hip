@@ -581,9 +581,15 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__
 // Multi-tensor weight packing: every conv weight of the model, forward layout (mode 0: [Cout][taps][Cg_pad], as pack_w_fwd_kernel) or
 // data-gradient layout (mode 1: [G][Cg][taps][Cn], as pack_w_dgrad_kernel), in ONE launch per step instead of two tiny launches per
 // conv.  desc[t] = {src fp32 OIHW, dst, a, b, c, taps, Kpad, mode}: mode 0: a = Cout, b = Cg, c = Cg_pad; mode 1: a = G, b = Cn, c = Cg.
+// A workgroup owns `chunk` consecutive OUTPUT elements of one tensor.  Both layouts are transposes of the OIHW source (tap <-> channel,
+// output <-> input channel): gathering element by element read 4 bytes out of every 36..4608 (170 + 250 us per step on S-3D for
+// 110 MB of traffic).  The data-gradient layout is staged through LDS: the source is read in runs that are contiguous in OIHW (the
+// R * taps weights that R consecutive input channels own in one filter), the packed rows are written contiguously (250 -> 117 us).
 template <typename T>
 __global__ __launch_bounds__(256) void mt_pack_w_kernel(const long* __restrict__ desc, const int* __restrict__ ctensor, const int* __restrict__ coff,
                                                         int chunk) {
+  constexpr int CAP = 4096;
+  __shared__ float st[CAP + 64];
   const long* d = desc + (long)ctensor[blockIdx.x] * 8;
   const float* __restrict__ w = (const float*)d[0];
   T* __restrict__ out = (T*)d[1];
@@ -591,24 +597,55 @@ __global__ __launch_bounds__(256) void mt_pack_w_kernel(const long* __restrict__
   const long n = mode == 0 ? (long)a * Kpad : (long)a * c * Kpad;
   const long beg = (long)coff[blockIdx.x] * chunk;
   const long end = beg + chunk < n ? beg + chunk : n;
-  for (long idx = beg + threadIdx.x; idx < end; idx += 256) {
-    const int k = (int)(idx % Kpad);
-    float v = 0.f;
-    if (mode == 0) {
-      const int co = (int)(idx / Kpad);
+  const int tid = threadIdx.x;
+  const long rb = beg / Kpad, re = (end - 1) / Kpad;  // packed rows this chunk touches
+  if (mode == 0) {
+    // row = output channel co, columns (tap, ci): consecutive lanes read OIHW addresses `taps` floats apart, all inside one filter
+    // (b * taps contiguous floats) - the lines are reused from L1/L2.  (Staging whole filters through LDS measured slower: 118 vs 89 us.)
+    for (long idx = beg + tid; idx < end; idx += 256) {
+      const int k = (int)(idx % Kpad), co = (int)(idx / Kpad);
+      float v = 0.f;
       if (k < taps * c) {
         const int tap = k / c, ci = k - tap * c;
         if (ci < b) v = w[((long)co * b + ci) * taps + tap];
       }
-    } else {
-      const int ci = (int)((idx / Kpad) % c);
-      const int g = (int)(idx / ((long)Kpad * c));
-      if (k < taps * b) {
-        const int tap = k / b, co = k - tap * b;
-        v = w[((long)(g * b + co) * c + ci) * taps + tap];
-      }
+      TT<T>::st(out + idx, v);
     }
-    TT<T>::st(out + idx, v);
+  } else {
+    // row = (g, ci); its columns are (tap, co).  Per pass: R consecutive input channels x CB output channels.
+    const int CB = b < 256 ? b : 256;
+    int R = CAP / (taps * (CB + 1));
+    if (R < 1) R = 1;
+    const int P = CB + 1;  // LDS pitch (odd: the transposing writes spread over the banks)
+    for (long r0 = rb; r0 <= re;) {
+      const int g = (int)(r0 / c), ci0 = (int)(r0 - (long)g * c);
+      int nr = R;
+      if (nr > c - ci0) nr = c - ci0;
+      if (nr > re - r0 + 1) nr = (int)(re - r0 + 1);
+      const int seg = nr * taps;
+      for (int co0 = 0; co0 < b; co0 += CB) {
+        const int cb = b - co0 < CB ? b - co0 : CB;
+        __syncthreads();
+        for (int i = tid; i < cb * seg; i += 256) {
+          const int col = i / seg, j = i - col * seg;
+          st[j * P + col] = w[((long)(g * b + co0 + col) * c + ci0) * taps + j];
+        }
+        __syncthreads();
+        for (int o = tid; o < seg * cb; o += 256) {
+          const int j = o / cb, col = o - j * cb;
+          const int cil = j / taps, tap = j - cil * taps;
+          const long idx = (r0 + cil) * Kpad + (long)tap * b + co0 + col;
+          if (idx >= beg && idx < end) TT<T>::st(out + idx, st[j * P + col]);
+        }
+      }
+      // row padding (Kpad - taps * b < 8 elements)
+      for (int o = tid; o < nr * (Kpad - taps * b); o += 256) {
+        const int rl = o / (Kpad - taps * b), k = taps * b + o - rl * (Kpad - taps * b);
+        const long idx = (r0 + rl) * Kpad + k;
+        if (idx >= beg && idx < end) TT<T>::st(out + idx, 0.f);
+      }
+      r0 += nr;
+    }
   }
 }
 
