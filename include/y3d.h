@@ -83,8 +83,10 @@ int y3d_conv2d_wgrad_splits(int dtype, int B, int Ho, int Wo, int Cout, int Cin_
 int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
 /* testing / A-B knob: 0 routes every convolution through the generic implicit-GEMM kernels; returns the previous value */
 int y3d_set_tile_kernels(int enable);
-/* same for the streaming 1x1 kernel (conv1x1_stream.hip: bf16 1x1 stride-1 forward / data gradient, LDS-resident weights) */
+/* same for the streaming 1x1 kernels (conv1x1_stream.hip: bf16 1x1 stride-1 forward / data gradient, LDS-resident weights;
+ * wgrad1x1_stream.hip: its weight gradient, LDS-DMA ring) */
 int y3d_set_stream1x1(int enable);
+int y3d_get_stream1x1(void);
 int y3d_get_tile_kernels(void);
 /* grad_oihw (+)= dL/dw.  Cin may be channel-padded (stem): only the first Cin_real channels are written. */
 int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,

@@ -558,9 +558,15 @@ def _conv1x1_abi(x, w, dy, bias=None, affine=None, stream=True):
         dxv = dx[:, lo:lo + Cin]
         dsb, dsh, dsw = ops.s3(dy)
         L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, H, W, Cout, wpd.data_ptr(), dxv.data_ptr(), dxv.stride(3), H, W, Cin, 1, 1, 1, 1, 0, st)
+        ns = L.conv2d_wgrad_plan(dt, B, H, W, Cin, Cout, 1, 1, 1, 1, 0)
+        slab = torch.full((ns * Cout * Cin,), float("nan"), dtype=torch.float32, device=DEV)
+        dW = torch.empty_like(wd)
+        L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, Cin, dy.data_ptr(), dsw, H, W, Cout, 1, 1, 1, 1, 0, slab.data_ptr(), ns,
+                            dW.data_ptr(), 0, st)
         torch.cuda.synchronize()
     finally:
         L.set_stream1x1(old)
+    _conv1x1_abi.dW = dW
     return y, part, dx
 
 
@@ -592,8 +598,13 @@ def test_stream1x1_matches_generic_kernel_and_exact_integer_conv(shape):
     L = y3d.lib()
     assert L.set_stream1x1(1) in (0, 1)
     y1, p1, dx1 = _conv1x1_abi((xt, lo, Cin), wf, dy, stream=True)
+    dw1 = _conv1x1_abi.dW
     y0, p0, dx0 = _conv1x1_abi((xt, lo, Cin), wf, dy, stream=False)
+    dw0 = _conv1x1_abi.dW
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    # weight gradient (wgrad1x1_stream.hip for Cin, Cout > 32): exact integers on these operands, whatever the split-K plan
+    dwr = torch.einsum("bohw,bihw->oi", dyf, xf[:, lo:lo + Cin])[:, :, None, None]
+    assert torch.equal(dw1.cpu(), dwr) and torch.equal(dw0.cpu(), dwr)
     yr = torch.nn.functional.conv2d(xf[:, lo:lo + Cin], wf)
     assert torch.equal(y1.float().cpu(), yr)
     dxr = torch.nn.functional.conv_transpose2d(dyf, wf)

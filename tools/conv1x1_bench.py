@@ -48,9 +48,18 @@ def run(L, st, dt, B, H, Cin, Cout, reps, stream_on):
         ysb, ysh, ysw = ops.s3(y)
         L.conv2d_bwd_data(dt, y.data_ptr(), ysb, ysh, ysw, B, H, H, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, H, Cin, 1, 1, 1, 1, 0, st)
 
+    ns = L.conv2d_wgrad_plan(dt, B, H, H, Cin, Cout, 1, 1, 1, 1, 0)
+    slab = torch.empty(ns * Cout * Cin, dtype=torch.float32, device=DEV)
+    dW = torch.empty_like(w)
+
+    def wgrad():
+        ysb, ysh, ysw = ops.s3(y)
+        L.conv2d_bwd_weight(dt, x.data_ptr(), sb, sh, sw, B, H, H, Cin, Cin, y.data_ptr(), ysw, H, H, Cout, 1, 1, 1, 1, 0, slab.data_ptr(), ns,
+                            dW.data_ptr(), 0, st)
+
     out = []
     try:
-        for fn in (fwd, dgrad):
+        for fn in (fwd, dgrad, wgrad):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -63,26 +72,26 @@ def run(L, st, dt, B, H, Cin, Cout, reps, stream_on):
             out.append(e0.elapsed_time(e1) / reps * 1e3)
     finally:
         L.set_stream1x1(old)
-    return out, y.clone(), part.double().sum(0), dx.clone()
+    return out, y.clone(), part.double().sum(0), dx.clone(), dW.clone()
 
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     L, st, dt = y3d.lib(), ops.stream(), BF16
     B = 32
-    print(f"{'shape':>22} {'fwd old':>9} {'fwd new':>9} {'TB/s':>6} {'dgrad old':>10} {'dgrad new':>10} {'TB/s':>6}  equal")
-    tot = [0.0, 0.0, 0.0, 0.0]
+    print(f"{'shape':>22} {'fwd old':>9} {'fwd new':>9} {'TB/s':>6} {'dgrad old':>10} {'dgrad new':>10} {'TB/s':>6} {'wgrad old':>10} {'wgrad new':>10} {'TF/s':>6}  equal")
+    tot = [0.0] * 6
     for H, Cin, Cout in SHAPES:
-        (fo, do), y0, p0, dx0 = run(L, st, dt, B, H, Cin, Cout, reps, False)
-        (fn, dn), y1, p1, dx1 = run(L, st, dt, B, H, Cin, Cout, reps, True)
+        (fo, do, wo), y0, p0, dx0, dw0 = run(L, st, dt, B, H, Cin, Cout, reps, False)
+        (fn, dn, wn), y1, p1, dx1, dw1 = run(L, st, dt, B, H, Cin, Cout, reps, True)
         M = B * H * H
         byt = M * (Cin + Cout) * 2
-        eq = bool(torch.equal(y0, y1)) and bool(torch.equal(dx0, dx1))
+        eq = bool(torch.equal(y0, y1)) and bool(torch.equal(dx0, dx1)) and bool(torch.equal(dw0, dw1))
         perr = float(((p0 - p1).abs() / (p0.abs() + 1e-3)).max())
-        print(f"{H:4d}x{H:<4d} {Cin:4d}->{Cout:<4d} {fo:9.1f} {fn:9.1f} {byt / fn / 1e6:6.2f} {do:10.1f} {dn:10.1f} {byt / dn / 1e6:6.2f}  {eq} stats rel {perr:.1e}")
-        for i, v in enumerate((fo, fn, do, dn)):
+        print(f"{H:4d}x{H:<4d} {Cin:4d}->{Cout:<4d} {fo:9.1f} {fn:9.1f} {byt / fn / 1e6:6.2f} {do:10.1f} {dn:10.1f} {byt / dn / 1e6:6.2f} {wo:10.1f} {wn:10.1f} {2.0 * M * Cin * Cout / wn / 1e6:6.0f}  {eq} stats rel {perr:.1e}")
+        for i, v in enumerate((fo, fn, do, dn, wo, wn)):
             tot[i] += v
-    print("sum us: fwd old %.0f new %.0f, dgrad old %.0f new %.0f" % tuple(tot))
+    print("sum us: fwd old %.0f new %.0f, dgrad old %.0f new %.0f, wgrad old %.0f new %.0f" % tuple(tot))
 
 
 if __name__ == "__main__":

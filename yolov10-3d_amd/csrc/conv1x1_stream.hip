@@ -281,6 +281,8 @@ void pw_launch_ns(const PwP& p, const PwPlan& pl, hipStream_t st) {
 
 static int g_stream1x1 = 1;
 
+extern "C" int y3d_get_stream1x1(void) { return g_stream1x1; }
+
 extern "C" int y3d_set_stream1x1(int enable) {
   const int old = g_stream1x1;
   g_stream1x1 = enable ? 1 : 0;

@@ -14,6 +14,7 @@
 // (sum, sum of squares per channel), which makes the BN statistics bitwise reproducible (no atomics).
 #include "common.h"
 #include "conv_frag.h"
+#include <cstdlib>
 
 namespace {
 
@@ -695,6 +696,10 @@ int y3d_conv3x3_wgrad_tile_launch(int th, const void* x, long xsb, long xsh, lon
 int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw);
 int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, const float* bias, const float* scale, const float* shift, int act,
                               void* y, long ysw, float* part, long M, int K, int N, void* stream);
+// wgrad1x1_stream.hip
+int y3d_wgrad1x1_stream_ok(int dtype, long M, int Cg, int Cn, long xsw, long dsw);
+int y3d_wgrad1x1_stream_launch(const void* x, long xsw, const void* dy, long dsw, long M, int Cg, int Cn, float* slab, int nsplit, int chunk_px,
+                               void* stream);
 static inline bool dense_pixels(int B, int H, int W, long sb, long sh, long sw) {
   return (H == 1 || sh == (long)W * sw) && (B == 1 || sb == (long)H * W * sw);
 }
@@ -718,6 +723,16 @@ int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int
   int th = (g_tile_kernels && groups > 0) ? y3d_wgrad_tile_height(dtype, H, W, Cin / groups, Cout / groups, kh, kw, stride, pad) : 0;
   if (th) return y3d_wgrad_tile_splits(th, B, H, W, Cin / groups, Cout / groups, groups);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && y3d_wgrad1x1_stream_ok(dtype, (long)B * H * W, Cin, Cout, Cin, Cout)) {
+    // the streaming kernel keeps one 512-thread workgroup per CU busy (148 KB of LDS ring): one round of workgroups, at least four
+    // 64-pixel steps each; every further split is one more fp32 slab to write and to fold
+    static int target = 0;
+    if (!target) { const char* e = getenv("Y3D_WG1_TARGET"); target = e ? atoi(e) : 256; }
+    const long tiles = (long)cdiv(Cin, Cin <= 64 ? 64 : 128) * cdiv(Cout, Cout <= 64 ? 64 : 128);
+    long want = cdiv(target, tiles), maxs = cdiv((long)B * H * W, 4 * 64);
+    if (want > maxs) want = maxs;
+    return (int)(want < 1 ? 1 : want);
+  }
   return y3d_conv2d_wgrad_splits(dtype, B, Ho, Wo, Cout, Cin / groups, groups, kh, kw);
 }
 
@@ -900,6 +915,14 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
       Y3D_LAUNCH_CHECK();
       return Y3D_OK;
     }
+  }
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && Cin_real == Cin && dense_pixels(B, H, W, xsb, xsh, xsw) &&
+      y3d_wgrad1x1_stream_ok(dtype, p.M, Cin, Cout, xsw, dsw)) {
+    int rc = y3d_wgrad1x1_stream_launch(x, xsw, dy, dsw, p.M, Cin, Cout, slab, nsplit, p.chunk_px, stream);
+    if (rc) return rc;
+    launch_wgrad_reduce(slab, grad_oihw, nsplit, Cout, 1, Cin, Cin, accumulate, st);
+    Y3D_LAUNCH_CHECK();
+    return Y3D_OK;
   }
   const int wd = wgrad_tile_w(p.Cn), wx = wgrad_tile_w(p.Ktot);
   dim3 grid(cdiv(p.Ktot, wx), cdiv(p.Cn, wd), groups * nsplit);
