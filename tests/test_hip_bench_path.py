@@ -672,3 +672,32 @@ def test_mt_pack_weights_matches_single_tensor_packing():
         torch.cuda.synchronize()
         for i, (w, ref, dst) in enumerate(ents):
             assert torch.equal(dst.view(torch.int16), ref.view(torch.int16)), (mode, i, tuple(w.shape))
+
+
+@pytest.mark.parametrize("kind", ["c2f", "c2f_shortcut", "sppf", "psa"])
+def test_concat_placement_is_bit_identical_to_copying(kind):
+    """C2f / SPPF producers write straight into their slice of the concat buffer (ops.place); with the switch off every input is copied.
+    Same kernels on the same values either way: outputs and gradients must not differ in a single bit.  PSA concatenates a slice of its
+    cv1 output with a new tensor: that slice must NOT be taken for an in-place input (its neighbour is still needed by the backward)."""
+    from importlib import import_module
+    M = import_module("yolov10-3d_amd.modules")
+    torch.manual_seed(3)
+    mod = {"c2f": lambda: M.C2f(64, 128, 2), "c2f_shortcut": lambda: M.C2f(64, 64, 1, True), "sppf": lambda: M.SPPF(128, 128),
+           "psa": lambda: M.PSA(128, 128)}[kind]().to(DEV).train()
+    x0 = torch.randn(2, mod.cv1.conv.in_channels, 20, 24, device=DEV)
+    res = []
+    old = ops.PLACEMENT
+    try:
+        for flag in (True, False):
+            ops.PLACEMENT = flag
+            ops.reset_placement()
+            for p in mod.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = mod(x)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=DEV).view(y.shape)).sum().backward()
+            res.append([y.detach().float().clone(), x.grad.clone()] + [p.grad.clone() for p in mod.parameters()])
+    finally:
+        ops.PLACEMENT = old
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

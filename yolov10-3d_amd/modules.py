@@ -144,8 +144,12 @@ class Bottleneck(nn.Module):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
-        return self.cv2(self.cv1(x), x, 1) if self.add else self.cv2(self.cv1(x))
+    def forward(self, x, place=None):
+        """place = (buffer, channel offset): the block's output goes straight into that slice (ops.place)"""
+        with ops.place(None, 0):
+            h = self.cv1(x)
+        with ops.place(*(place or (None, 0))):
+            return self.cv2(h, x, 1) if self.add else self.cv2(h)
 
 
 class C2f(nn.Module):
@@ -159,8 +163,13 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
     def forward(self, x):
-        y = list(self.cv1(x).chunk(2, 1))
-        y.extend(m(y[-1]) for m in self.m)
+        # cv1 and the blocks write into their slices of ONE buffer: the reference's torch.cat (block.py:236) costs nothing
+        buf = ops.concat_buffer(x, (2 + len(self.m)) * self.c)
+        with ops.place(buf, 0):
+            t = self.cv1(x)
+        y = list(t.chunk(2, 1))
+        for i, m in enumerate(self.m):
+            y.append(m(y[-1], place=(buf, (2 + i) * self.c)) if isinstance(m, Bottleneck) else m(y[-1]))
         return self.cv2(cat(y))
 
 
@@ -175,11 +184,15 @@ class SPPF(nn.Module):
         self.k = k
 
     def forward(self, x):
-        x = self.cv1(x)
-        y1 = ops.MaxPoolFn.apply(x, self.k)
-        y2 = ops.MaxPoolFn.apply(y1, self.k)
-        y3 = ops.MaxPoolFn.apply(y2, self.k)
-        return self.cv2(cat((x, y1, y2, y3)))
+        c_ = self.cv1.conv.out_channels
+        buf = ops.concat_buffer(x, 4 * c_)
+        ys = []
+        with ops.place(buf, 0):
+            ys.append(self.cv1(x))
+        for i in range(1, 4):
+            with ops.place(buf, i * c_):
+                ys.append(ops.MaxPoolFn.apply(ys[-1], self.k))
+        return self.cv2(cat(ys))
 
 
 class RepVGGDW(nn.Module):

@@ -54,6 +54,63 @@ def nhwc_empty(B, C, H, W, dtype, device):
     return torch.empty((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
+# ---- output placement: a producer writes its result straight into a channel slice of its consumer's concat buffer ----------------
+# (C2f / SPPF / Upsample -> Concat: the reference's torch.cat, block.py:236 / :176, conv.py:404, becomes a no-op instead of one copy per
+# input; every kernel on this path takes a pixel stride, so a channel slice of a wider NHWC buffer is an ordinary operand.)
+PLACEMENT = not os.environ.get("Y3D_NO_PLACE")  # A/B switch
+_PLACE = None
+
+
+class place:
+    """`with place(buf, off): y = producer(x)` - the next output tensor of matching batch / spatial shape and dtype allocated by a
+    kernel wrapper inside the block is `buf[:, off:off + C]` instead of a fresh tensor (consumed by the first match)."""
+
+    def __init__(self, buf, off):
+        self.t = (buf, off) if buf is not None else None
+
+    def __enter__(self):
+        global _PLACE
+        self.prev, _PLACE = _PLACE, self.t
+
+    def __exit__(self, *a):
+        global _PLACE
+        _PLACE = self.prev
+
+
+def concat_buffer(x, C, H=None, W=None):
+    """the buffer a group of producers will fill for a channel concat of C channels at x's batch / spatial size, or None"""
+    dtype = _COMPUTE_DTYPE
+    if not PLACEMENT or not x.is_cuda or C % ce(dtype) != 0:
+        return None
+    buf = nhwc_empty(x.shape[0], C, x.shape[2] if H is None else H, x.shape[3] if W is None else W, dtype, x.device)
+    _CONCAT_BASE[buf.data_ptr()] = C
+    return buf
+
+
+# addresses of the live concat buffers: ConcatFn only trusts "already in place" for slices of a buffer made by concat_buffer (a PSA
+# block concatenates a slice of its cv1 output with a NEW tensor: that slice has the right strides too, and filling "its" buffer would
+# overwrite the other half, which the backward still needs).  An entry dies with its ConcatFn; a model forward starts from none.
+_CONCAT_BASE = {}
+
+
+def reset_placement():
+    global _PLACE
+    _PLACE = None
+    _CONCAT_BASE.clear()
+
+
+def out_tensor(B, C, H, W, dtype, device):
+    """nhwc_empty, or the placement slice if one is pending and fits"""
+    global _PLACE
+    if _PLACE is not None:
+        buf, off = _PLACE
+        if (buf.dtype == dtype and buf.shape[0] == B and buf.shape[2] == H and buf.shape[3] == W and off + C <= buf.shape[1]
+                and off % ce(dtype) == 0 and C % ce(dtype) == 0 and buf.device == device):
+            _PLACE = None
+            return buf[:, off:off + C]
+    return nhwc_empty(B, C, H, W, dtype, device)
+
+
 def is_nhwc(x: torch.Tensor) -> bool:
     return x.dim() == 4 and (x.stride(1) == 1 or x.shape[1] == 1)
 
@@ -413,13 +470,13 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     if not bn_apply:  # the consumer applies BatchNorm + activation itself (FusedConvBNProjFn): hand back the pre-BN tensor
         cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
         return y, cfg, (xin, w32, y, stats, None)
-    z = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+    z = out_tensor(B, Cout, Ho, Wo, dtype, dev)
     rr = None
     if res_mode:
         rr = to_nhwc(res, dtype, dense=True)
         assert rr.shape == z.shape, "residual shape mismatch"
     L.bn_act_fwd(dt, y.data_ptr(), Cout, stats[2].data_ptr(), stats[3].data_ptr(), int(act), res_mode,
-                 rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), Cout, M, Cout, st)
+                 rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), z.stride(3), M, Cout, st)
     # [17]: version token of the weights as packed (stacked views / fp8 shadows carry their identity outside the tensor's own counter)
     cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
@@ -964,17 +1021,33 @@ class ConcatFn(torch.autograd.Function):
         dtype = _COMPUTE_DTYPE
         dt = code(dtype)
         st = stream()
-        xs = [to_nhwc(x, dtype, dense=True) for x in xs]
         B, _, H, W = xs[0].shape
         cs = [x.shape[1] for x in xs]
         tot = sum(cs)
-        out = nhwc_empty(B, tot, H, W, dtype, xs[0].device)
-        esz = out.element_size()
-        off = 0
-        for x, c in zip(xs, cs):
-            L.copy2d(dt, x.data_ptr(), x.stride(3), out.data_ptr() + off * esz, tot, B * H * W, c, st)
-            off += c
         ctx.cs = cs
+        # inputs that already sit in their slice of one tot-channel NHWC buffer (ops.place) are not copied
+        esz = 2 if dtype == torch.bfloat16 else 4
+        out, inplace, off = None, [False] * len(xs), 0
+        for i, (x, c) in enumerate(zip(xs, cs)):
+            if (PLACEMENT and x.dtype == dtype and x.is_cuda and is_nhwc(x) and x.stride(3) == tot and x.stride(2) == W * tot
+                    and x.stride(0) == H * W * tot):
+                base = x.data_ptr() - off * esz
+                if out is None and _CONCAT_BASE.get(base) == tot:
+                    del _CONCAT_BASE[base]
+                    out = torch.as_strided(x, (B, tot, H, W), x.stride(), x.storage_offset() - off)
+                    assert out.data_ptr() == base
+                    inplace[i] = True
+                elif out is not None and out.data_ptr() == base:
+                    inplace[i] = True
+            off += c
+        if out is None:
+            out = nhwc_empty(B, tot, H, W, dtype, xs[0].device)
+        off = 0
+        for i, (x, c) in enumerate(zip(xs, cs)):
+            if not inplace[i]:
+                x = to_nhwc(x, dtype, dense=True)
+                L.copy2d(dt, x.data_ptr(), x.stride(3), out.data_ptr() + off * esz, tot, B * H * W, c, st)
+            off += c
         return out
 
     @staticmethod
@@ -996,11 +1069,11 @@ class MaxPoolFn(torch.autograd.Function):
         dt = code(dtype)
         x = to_nhwc(x, dtype)
         B, C, H, W = x.shape
-        y = nhwc_empty(B, C, H, W, dtype, x.device)
+        y = out_tensor(B, C, H, W, dtype, x.device)
         need = x.requires_grad
         arg = torch.empty(B * H * W * C, dtype=torch.uint8, device=x.device) if need else None
         sb, sh, sw = s3(x)
-        L.maxpool_fwd(dt, x.data_ptr(), sb, sh, sw, y.data_ptr(), C, arg.data_ptr() if need else None, B, H, W, C, k, stream())
+        L.maxpool_fwd(dt, x.data_ptr(), sb, sh, sw, y.data_ptr(), y.stride(3), arg.data_ptr() if need else None, B, H, W, C, k, stream())
         ctx.k = k
         ctx.dtype = dtype
         if need:
@@ -1028,9 +1101,9 @@ class Upsample2xFn(torch.autograd.Function):
         dtype = _COMPUTE_DTYPE
         x = to_nhwc(x, dtype)
         B, C, H, W = x.shape
-        y = nhwc_empty(B, C, 2 * H, 2 * W, dtype, x.device)
+        y = out_tensor(B, C, 2 * H, 2 * W, dtype, x.device)
         sb, sh, sw = s3(x)
-        L.upsample2x_fwd(code(dtype), x.data_ptr(), sb, sh, sw, y.data_ptr(), C, B, H, W, C, stream())
+        L.upsample2x_fwd(code(dtype), x.data_ptr(), sb, sh, sw, y.data_ptr(), y.stride(3), B, H, W, C, stream())
         ctx.dtype = dtype
         return y
 

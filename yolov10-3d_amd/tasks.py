@@ -23,6 +23,7 @@ from ._lib import Y3DError
 import yaml
 
 from . import modules as M
+from . import ops
 from .modules import (C2f, C2fCIB, Concat, Conv, Detect, DWConv, PSA, SCDown, SPPF, Upsample, v10Detect, v10Detect3d)
 
 CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg", "models")
@@ -225,12 +226,39 @@ class BaseModel(nn.Module):
 
     def _predict_once(self, x):
         y = []
-        for m in self.model:
+        ops.reset_placement()
+        layers = list(self.model)
+        for idx, m in enumerate(layers):
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x)
+            with ops.place(self._concat_slot(layers, idx, x, y), 0):
+                x = m(x)
             y.append(x if m.i in self.save else None)
         return x
+
+    @staticmethod
+    def _concat_slot(layers, idx, x, y):
+        """A single-kernel producer (Upsample, Conv) whose output is the FIRST input of the next row's Concat writes it straight into the
+        concat buffer (ops.place); the other inputs are copied in by ConcatFn.  None: nothing to place."""
+        m = layers[idx]
+        nxt = layers[idx + 1] if idx + 1 < len(layers) else None
+        if not (type(nxt) is Concat and isinstance(nxt.f, (list, tuple)) and len(nxt.f) >= 2 and nxt.f[0] == -1 and m.f == -1
+                and torch.is_tensor(x) and x.dim() == 4):
+            return None
+        others = [y[j] if j >= 0 else y[len(y) + 1 + j] if len(y) + 1 + j >= 0 else None for j in nxt.f[1:]]
+        if any(o is None or not torch.is_tensor(o) for o in others):
+            return None
+        if type(m) is Upsample:
+            c, h, w = x.shape[1], 2 * x.shape[2], 2 * x.shape[3]
+        elif type(m) is Conv:
+            c = m.conv.out_channels
+            h = (x.shape[2] + 2 * m.p - m.k) // m.s + 1
+            w = (x.shape[3] + 2 * m.p - m.k) // m.s + 1
+        else:
+            return None
+        if any(o.shape[2] != h or o.shape[3] != w for o in others):
+            return None
+        return ops.concat_buffer(x, c + sum(o.shape[1] for o in others), h, w)
 
     def loss(self, batch, preds=None):
         if not hasattr(self, "criterion"):
