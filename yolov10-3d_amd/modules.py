@@ -167,9 +167,15 @@ class C2f(nn.Module):
         buf = ops.concat_buffer(x, (2 + len(self.m)) * self.c)
         with ops.place(buf, 0):
             t = self.cv1(x)
-        y = list(t.chunk(2, 1))
+        if t.is_cuda and t.shape[1] == 2 * self.c and self.c % ops.ce(ops.compute_dtype()) == 0:
+            y0, y1, feed = ops.C2fSplitFn.apply(t)  # y1 twice: once for the concat, once for the first block
+        else:
+            y0, y1 = t.chunk(2, 1)
+            feed = y1
+        y = [y0, y1]
         for i, m in enumerate(self.m):
-            y.append(m(y[-1], place=(buf, (2 + i) * self.c)) if isinstance(m, Bottleneck) else m(y[-1]))
+            feed = m(feed, place=(buf, (2 + i) * self.c)) if isinstance(m, Bottleneck) else m(feed)
+            y.append(feed)
         return self.cv2(cat(y))
 
 

@@ -716,6 +716,52 @@ class SplitChannelsFn(torch.autograd.Function):
         return dx, None, None
 
 
+class C2fSplitFn(torch.autograd.Function):
+    """`y = list(cv1(x).chunk(2, 1))` of C2f (reference block.py:233) with the second half handed out TWICE (it feeds the first block and
+    the concat): -> (y0, y1 for the concat, y1 for the block), all views.  Plain chunk + reuse makes autograd (a) add the two
+    gradients of y1 with a strided-operand elementwise kernel and (b) assemble the gradient of the chunked tensor from zero-filled
+    full-size pieces.  Here the backward adds the block's gradient INTO the concat gradient's slice (`y3d_add2d`, in place: that slice
+    of the concat gradient has no other reader) and returns the first two slices of that buffer as one strided view - no copy at all
+    when the two concat gradients are neighbours in one buffer, one gather otherwise."""
+
+    @staticmethod
+    def forward(ctx, t):
+        c = t.shape[1] // 2
+        ctx.c = c
+        return t[:, :c], t[:, c:], t[:, c:]
+
+    @staticmethod
+    def backward(ctx, d0, d1a, d1b):
+        L, st, c = lib(), stream(), ctx.c
+        ref = next(g for g in (d0, d1a, d1b) if g is not None)
+        dtype, dev = ref.dtype, ref.device
+        B, _, H, W = ref.shape
+        dt = code(dtype)
+        esz = ref.element_size()
+        P = B * H * W
+        ok = lambda g: g is not None and g.dtype == dtype and is_nhwc(g) and g.data_ptr() % 16 == 0 and g.stride(3) % ce(dtype) == 0 and px_dense(g)
+        if (d0 is not None and d1a is not None and ok(d0) and ok(d1a) and d0.stride() == d1a.stride()
+                and d1a.data_ptr() == d0.data_ptr() + c * esz and d0.stride(3) >= 2 * c):
+            if d1b is not None:
+                d1b = to_nhwc(d1b, dtype, dense=True)
+                L.add2d(dt, d1a.data_ptr(), d1a.stride(3), d1b.data_ptr(), d1b.stride(3), d1a.data_ptr(), d1a.stride(3), P, c, st)
+            return torch.as_strided(d0, (B, 2 * c, H, W), d0.stride(), d0.storage_offset())
+        out = nhwc_empty(B, 2 * c, H, W, dtype, dev)
+        if d0 is None:
+            out[:, :c].zero_()
+        else:
+            d0 = to_nhwc(d0, dtype, dense=True)
+            L.copy2d(dt, d0.data_ptr(), d0.stride(3), out.data_ptr(), 2 * c, P, c, st)
+        parts = [to_nhwc(g, dtype, dense=True) for g in (d1a, d1b) if g is not None]
+        if not parts:
+            out[:, c:].zero_()
+        elif len(parts) == 1:
+            L.copy2d(dt, parts[0].data_ptr(), parts[0].stride(3), out.data_ptr() + c * esz, 2 * c, P, c, st)
+        else:
+            L.add2d(dt, parts[0].data_ptr(), parts[0].stride(3), parts[1].data_ptr(), parts[1].stride(3), out.data_ptr() + c * esz, 2 * c, P, c, st)
+        return out
+
+
 # ------------------------------------------------------------------------------------------------------
 # plain nn.Conv2d(c, out, 1) with bias (head projections)
 # ------------------------------------------------------------------------------------------------------
