@@ -89,20 +89,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
   // Per K step the address is base + (tap offset + channel), i.e. one 64-bit add and one mask test per 16-byte chunk.
   const int cc = tid & 7;
   const int r0 = tid >> 3;
-  const long SH = DGRAD ? p.xsh / p.stride : p.xsh;  // dgrad: (t/s)*xsh == t*(xsh/s) for the taps the mask admits
-  const long SW = DGRAD ? p.xsw / p.stride : p.xsw;
+  // dgrad: (t/s)*xsh == t*(xsh/s) for the taps the mask admits (no 64-bit division for the strides the models use)
+  const long SH = !DGRAD || p.stride == 1 ? p.xsh : (p.stride == 2 ? p.xsh >> 1 : p.xsh / p.stride);
+  const long SW = !DGRAD || p.stride == 1 ? p.xsw : (p.stride == 2 ? p.xsw >> 1 : p.xsw / p.stride);
   const T* aptr[RA];
   unsigned long long amask[RA];
+  // pixel coordinates of the first row by division, of the following ones (32 pixels further each) by carry
+  int rb_ = (p0 + r0) / (Hc * Wc), rh_, rw_;
+  {
+    const int rem = (p0 + r0) - rb_ * (Hc * Wc);
+    rh_ = rem / Wc;
+    rw_ = rem - rh_ * Wc;
+  }
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     int m = p0 + r0 + 32 * i;
     aptr[i] = X;
     amask[i] = 0ull;
+    if (i) {
+      rw_ += 32;
+      while (rw_ >= Wc) { rw_ -= Wc; ++rh_; }
+      while (rh_ >= Hc) { rh_ -= Hc; ++rb_; }
+    }
     if (m < Mc) {
-      int b = m / (Hc * Wc);
-      int rem = m - b * (Hc * Wc);
-      int hq = rem / Wc;
-      int wq = rem - hq * Wc;
+      int b = rb_;
+      int hq = rh_;
+      int wq = rw_;
       if (MODE == 2) { hq = 2 * hq + py; wq = 2 * wq + px; }
       int a_h = DGRAD ? hq + p.pad : hq * p.stride - p.pad;
       int a_w = DGRAD ? wq + p.pad : wq * p.stride - p.pad;
@@ -112,8 +124,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvP p) {
         for (int q = 0; q < p.kw; ++q) {
           bool ok;
           if (DGRAD) {
+            // strides 1 and 2 without an integer division: 9 taps x 4 rows x 2 divisions per thread were most of a workgroup's life on
+            // the short-K launches (3x3 stride-2 data gradient by parity class at 320x320: 25 600 workgroups of one to four K steps)
             int th = a_h - r, tw = a_w - q;
-            int hh = th / p.stride, ww = tw / p.stride;
+            int hh, ww;
+            if (p.stride == 1) { hh = th; ww = tw; }
+            else if (p.stride == 2) { hh = th >> 1; ww = tw >> 1; }
+            else { hh = th / p.stride; ww = tw / p.stride; }
             ok = th >= 0 && tw >= 0 && hh * p.stride == th && ww * p.stride == tw && hh < p.Hg && ww < p.Wg;
           } else {
             int hh = a_h + r, ww = a_w + q;
