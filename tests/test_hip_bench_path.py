@@ -701,3 +701,46 @@ def test_concat_placement_is_bit_identical_to_copying(kind):
         ops.PLACEMENT = old
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+S2_SHAPES = [
+    # B, H, W, Cin, Cout
+    (2, 64, 64, 32, 64),      # the 320 -> 160 layer's geometry in small
+    (3, 34, 38, 64, 128),     # two K slabs, ragged tiles, two input-channel blocks
+    (2, 17, 21, 128, 128),    # odd image: the last dx row / column has no odd-parity taps
+    (1, 40, 24, 24, 64),      # input channels not a multiple of 32
+]
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3s2_dgrad_resident_tile_matches_generic_and_exact(shape):
+    """conv3x3s2_dgrad.hip (all four parity classes from one dy tile) against the generic parity-class kernel (bit-identical: same
+    accumulation order) and against fp32 conv_transpose2d on small-integer operands (exact)."""
+    L, st, dt = y3d.lib(), ops.stream(), BF16
+    B, H, W, Cin, Cout = shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator().manual_seed(sum(shape))
+    wf = _sparse_int((Cout, Cin, 3, 3), g, 0.25)
+    dyf = _sparse_int((B, Cout, Ho, Wo), g, 0.25)
+    dy = ops.nhwc_empty(B, Cout, Ho, Wo, torch.bfloat16, DEV)
+    dy.copy_(dyf.to(DEV))
+    wd = wf.to(DEV).contiguous()
+    kp = L.conv_kpad(dt, 9 * Cout)
+    wpd = torch.empty(Cin * kp, dtype=torch.bfloat16, device=DEV)
+    L.pack_weight_dgrad(dt, wd.data_ptr(), wpd.data_ptr(), Cout, Cin, 1, 3, 3, st)
+    dsb, dsh, dsw = ops.s3(dy)
+    outs = []
+    for flag in (1, 0):
+        old = L.set_stream1x1(flag)
+        try:
+            dx = ops.nhwc_empty(B, Cin, H, W, torch.bfloat16, DEV)
+            dx.fill_(float("nan"))
+            L.conv2d_bwd_data(dt, dy.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, Cout, wpd.data_ptr(), dx.data_ptr(), Cin, H, W, Cin, 1, 3, 3, 2, 1, st)
+            torch.cuda.synchronize()
+        finally:
+            L.set_stream1x1(old)
+        outs.append(dx.float().cpu())
+    ref = torch.nn.functional.conv_transpose2d(dyf, wf, stride=2, padding=1, output_padding=(H - 1 - 2 * (Ho - 1), W - 1 - 2 * (Wo - 1)))
+    assert ref.shape == outs[0].shape
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], ref)

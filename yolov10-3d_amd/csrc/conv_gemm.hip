@@ -717,6 +717,10 @@ int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, 
 int y3d_wgrad1x1_stream_ok(int dtype, long M, int Cg, int Cn, long xsw, long dsw);
 int y3d_wgrad1x1_stream_launch(const void* x, long xsw, const void* dy, long dsw, long M, int Cg, int Cn, float* slab, int nsplit, int chunk_px,
                                void* stream);
+// conv3x3s2_dgrad.hip
+int y3d_conv3x3s2_dgrad_ok(int dtype, int B, int Ho, int Wo, int H, int W, int Cout, int Cin, long dsw, long xsw);
+int y3d_conv3x3s2_dgrad_launch(const void* dy, long dsw, int B, int Ho, int Wo, int Cout, const void* w_packed_dgrad, int Kpad, void* dx, long xsw,
+                               int H, int W, int Cin, void* stream);
 static inline bool dense_pixels(int B, int H, int W, long sb, long sh, long sw) {
   return (H == 1 || sh == (long)W * sw) && (B == 1 || sb == (long)H * W * sw);
 }
@@ -868,6 +872,9 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
       y3d_conv1x1_stream_ok(dtype, p.M, Cout, Cin, dsw))
     return y3d_conv1x1_stream_launch(dy, dsw, w_packed_dgrad, p.Kpad, nullptr, nullptr, nullptr, 0, dx, xsw, nullptr, p.M, Cout, Cin, stream);
+  if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
+      y3d_conv3x3s2_dgrad_ok(dtype, B, Ho, Wo, H, W, Cout, Cin, dsw, xsw))
+    return y3d_conv3x3s2_dgrad_launch(dy, dsw, B, Ho, Wo, Cout, w_packed_dgrad, p.Kpad, dx, xsw, H, W, Cin, stream);
   if (g_tile_kernels) {
     // a 3x3 s1 p1 data gradient is the same conv on dy with flipped taps (Ho == H, Wo == W)
     int th = y3d_tile_height(dtype, B, Ho, Wo, p.Cg, p.Cn, groups, kh, kw, stride, pad);
