@@ -22,6 +22,7 @@
 // The K order of the accumulation (32-element MFMA steps, ascending) is the generic kernel's, so the outputs are bit-identical to it.
 #include "common.h"
 #include "conv_frag.h"
+#include <cstdlib>
 
 namespace {
 
@@ -35,7 +36,7 @@ struct PwP {
   int xsw;      // pixel stride of x in elements
   int M, K, N, Kpad;
   int nkc, nmt, nnt, act;
-  unsigned xbytes, ybytes, pbytes;
+  unsigned xbytes, ybytes, pbytes, wbytes;
 };
 
 template <int N> __device__ __forceinline__ void pw_wvm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -55,15 +56,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned pw_u32x2;
 // AFF: bias or folded affine (+ SiLU) in the epilogue.  A template parameter, not a run-time test: the compiler puts the
 // s_waitcnt vmcnt(0) for those per-channel loads at the join point of the branch, where it runs - and drains the ring - even
 // when nothing was loaded.
-template <int BN, int WP, int WC, int NS, bool AFF>
+// WRES: the weight tile [BN][K] is resident in LDS; otherwise (K x BN too large: the 40x40 / 20x20 layers with K, N >= 256) its 64-deep
+// chunk travels in the ring next to the pixel chunk (a stage is 16 KB of pixels + BN x 128 B of weights, the weights out of L2).
+template <int BN, int WP, int WC, int NS, bool AFF, bool WRES>
 __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
   constexpr int BM = 128;
   constexpr int TP = BM / WP / 16, TC = BN / WC / 16;
   static_assert(WP * WC == 8 && TP >= 1 && TC >= 1, "8 waves");
-  constexpr int STAGE = BM * 128;
+  constexpr int STAGE = BM * 128 + (WRES ? 0 : BN * 128);
+  constexpr int ND = 2 + (WRES ? 0 : BN / 64);   // DMA instructions per wave per stage
+  static_assert(WRES || BN % 64 == 0, "streamed weight tiles: whole DMA instructions per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sW = smem;                               // [nkc][BN][128 B]
-  char* sA = smem + (size_t)p.nkc * BN * 128;    // [NS][128][128 B]
+  char* sW = smem;                                              // [nkc][BN][128 B]  (resident weights)
+  char* sA = smem + (WRES ? (size_t)p.nkc * BN * 128 : 0);      // [NS][128 pixel rows | BN weight rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave % WP, wc = wave / WP;
   // XCD x gets workers x, x + 8, ...; the nnt channel tiles of one worker sit on the same XCD (they stream the same pixels)
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
   if (S == 0) return;
 
   // ---- resident weights ----------------------------------------------------------------------------------------------------------
+  if (WRES)
   for (int i = tid; i < p.nkc * BN * 8; i += 512) {
     const int c = i & 7, r = (i >> 3) % BN, kc = i / (8 * BN);
     const int k = kc * 64 + c * 8, n = n0 + r;
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
 
   // ---- DMA issue cursor ----------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
   constexpr unsigned OOB = 0xfffffff0u;
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;  // row inside an 8-row DMA instruction, global chunk it fetches
   int is = 0, i_tile = wk, i_kc = 0, i_slot = 0;
@@ -98,6 +105,16 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
       const bool ok = live & (m < p.M) & (k < p.K);
       const unsigned off = (unsigned)(m * p.xsw + k) * 2u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sA + i_slot * STAGE + r * 128), 16, ok ? off : OOB, 0, 0, 0);
+    }
+    if (!WRES) {
+#pragma unroll
+      for (int h = 0; h < BN / 64; ++h) {
+        const int r = (BN / 8) * wave + 8 * h;  // weight rows of this instruction: r .. r + 7
+        const int n = n0 + r + lrow;
+        const bool ok = live & (n < p.N) & (k < p.K);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sA + i_slot * STAGE + (BM + r) * 128), 16,
+                                                 ok ? (unsigned)(n * p.Kpad + k) * 2u : OOB, 0, 0, 0);
+      }
     }
     ++is;
     if (++i_kc == p.nkc) { i_kc = 0; i_tile += nwk; }
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
 #pragma unroll 1
   for (int s = 0; s < S; ++s) {
     {
-      int young = 2 * (NS - 2);
+      int young = ND * (NS - 2);
 #pragma unroll
       for (int i = 0; i < NS - 1; ++i) young += hist[i];
       pw_wvm_n(young);
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
         for (int b = 0; b < TP; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     const char* tA = sA + c_slot * STAGE + (wp * (BM / WP)) * 128;
-    const char* tW = sW + (c_kc * BN + wc * (BN / WC)) * 128;
+    const char* tW = WRES ? sW + (c_kc * BN + wc * (BN / WC)) * 128 : sA + c_slot * STAGE + (BM + wc * (BN / WC)) * 128;
     const int nks = p.K - c_kc * 64 >= 64 ? 2 : 1;
     for (int ks = 0; ks < nks; ++ks) {
       bf16x8_t fb[TP], fa[TC];
@@ -230,14 +247,17 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
 }
 
 struct PwPlan {
-  int bn, ns, nnt, grid;
+  int bn, ns, nnt, grid, wres;
   size_t lds;
 };
 
-// BN: the smallest tile covering N whose resident weights leave room for a 3-stage ring; otherwise the largest that fits
+// Resident weights: BN = the smallest tile covering N whose weights leave room for a 3-stage ring; otherwise the largest that fits.
+// More than two channel tiles would stream the pixels again and again (and a 64-channel tile with a six-stage ring measured 20-60 %
+// slower than the generic kernel on the 40x40 / 20x20 layers): those layers stream their weight chunk through the ring instead.
 bool pw_plan(int M, int K, int N, PwPlan* pl) {
   const int nkc = cdiv(K, 64);
   const size_t cap = 160 * 1024;
+  const int nmt = cdiv(M, 128);
   const int bns[4] = {256, 128, 64, 32};
   int bn = 0;
   for (int i = 0; i < 4; ++i) {
@@ -245,13 +265,28 @@ bool pw_plan(int M, int K, int N, PwPlan* pl) {
     if (i < 3 && bns[i + 1] >= N) continue;  // a smaller tile still covers N
     if ((size_t)b * nkc * 128 + 3 * 16384 <= cap) { bn = b; break; }
   }
-  if (!bn) return false;
-  const size_t wb = (size_t)bn * nkc * 128;
-  pl->bn = bn;
-  pl->ns = wb + 4 * 16384 <= cap ? 4 : 3;
-  pl->lds = wb + pl->ns * 16384;
-  pl->nnt = cdiv(N, bn);
-  const int nmt = cdiv(M, 128);
+  static const char* force = getenv("Y3D_PW_STREAMW");  // probe knob: 1 = streamed weights wherever they apply, 0 = never
+  const bool can_stream = N > 64 && nkc >= 2;
+  // two resident channel tiles stream the pixels twice: one streamed 256-channel tile measured 15-20 % faster at 40x40 (384 -> 256,
+  // 256 -> 256), slower on the 20x20 maps (too few pixel tiles to amortise the weight chunks)
+  bool wres = bn != 0 && (cdiv(N, bn) == 1 || (cdiv(N, bn) == 2 && nmt < 200));
+  if (force && can_stream) wres = atoi(force) == 0 && bn != 0;
+  if (!wres && !can_stream) {
+    if (!bn) return false;
+    wres = true;
+  }
+  pl->wres = wres;
+  if (wres) {
+    const size_t wb = (size_t)bn * nkc * 128;
+    pl->bn = bn;
+    pl->ns = wb + 4 * 16384 <= cap ? 4 : 3;
+    pl->lds = wb + pl->ns * 16384;
+  } else {
+    pl->bn = N > 128 ? 256 : 128;
+    pl->ns = pl->bn == 256 ? 3 : 4;
+    pl->lds = (size_t)pl->ns * (16384 + pl->bn * 128);
+  }
+  pl->nnt = cdiv(N, pl->bn);
   const int per_cu = pl->lds <= 80 * 1024 ? 2 : 1;
   int wpx = (32 * per_cu) / pl->nnt;  // workers per XCD
   if (wpx < 1) wpx = 1;
@@ -260,21 +295,21 @@ bool pw_plan(int M, int K, int N, PwPlan* pl) {
   return true;
 }
 
-template <int BN, int WP, int WC, int NS, bool AFF>
+template <int BN, int WP, int WC, int NS, bool AFF, bool WRES>
 void pw_launch_1(const PwP& p, const PwPlan& pl, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<BN, WP, WC, NS, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<BN, WP, WC, NS, AFF, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv1x1_stream_kernel<BN, WP, WC, NS, AFF>), dim3(pl.grid), dim3(512), pl.lds, st, p);
+  hipLaunchKernelGGL((conv1x1_stream_kernel<BN, WP, WC, NS, AFF, WRES>), dim3(pl.grid), dim3(512), pl.lds, st, p);
 }
 
 template <int BN, int WP, int WC>
 void pw_launch_ns(const PwP& p, const PwPlan& pl, hipStream_t st) {
   const bool aff = p.bias || p.scale;
-  if (pl.ns == 4) { if (aff) pw_launch_1<BN, WP, WC, 4, true>(p, pl, st); else pw_launch_1<BN, WP, WC, 4, false>(p, pl, st); }
-  else { if (aff) pw_launch_1<BN, WP, WC, 3, true>(p, pl, st); else pw_launch_1<BN, WP, WC, 3, false>(p, pl, st); }
+  if (pl.ns == 4) { if (aff) pw_launch_1<BN, WP, WC, 4, true, true>(p, pl, st); else pw_launch_1<BN, WP, WC, 4, false, true>(p, pl, st); }
+  else { if (aff) pw_launch_1<BN, WP, WC, 3, true, true>(p, pl, st); else pw_launch_1<BN, WP, WC, 3, false, true>(p, pl, st); }
 }
 
 }  // namespace
@@ -296,9 +331,7 @@ int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw) {
   if ((M * xsw + K) * 2 >= (1L << 32) - 64 || M * N * 2 >= (1L << 31)) return 0;
   PwPlan pl;
   if (!pw_plan((int)M, K, N, &pl)) return 0;
-  // more channel tiles than two stream the pixels again and again, and a smaller tile with a deeper ring (64 channels, 6 stages) measured
-  // 20-60 % SLOWER than the generic kernel on the 40x40 / 20x20 layers (K >= 256, N >= 256): those stay on conv_gemm.hip
-  return pl.nnt <= 2;
+  return 1;
 }
 
 int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, const float* bias, const float* scale, const float* shift, int act,
@@ -316,6 +349,14 @@ int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, 
   p.ybytes = (unsigned)(((M - 1) * ysw + N) * 2);
   p.pbytes = part ? (unsigned)((long)p.nmt * N * 8) : 0u;
   hipStream_t st = (hipStream_t)stream;
+  p.wbytes = (unsigned)((long)N * Kpad * 2);
+  if (!pl.wres) {
+    const bool aff = bias || scale;
+    if (pl.bn == 256) { if (aff) pw_launch_1<256, 2, 4, 3, true, false>(p, pl, st); else pw_launch_1<256, 2, 4, 3, false, false>(p, pl, st); }
+    else { if (aff) pw_launch_1<128, 4, 2, 4, true, false>(p, pl, st); else pw_launch_1<128, 4, 2, 4, false, false>(p, pl, st); }
+    Y3D_LAUNCH_CHECK();
+    return Y3D_OK;
+  }
   switch (pl.bn) {
     case 256: pw_launch_ns<256, 2, 4>(p, pl, st); break;
     case 128: pw_launch_ns<128, 4, 2>(p, pl, st); break;
