@@ -578,6 +578,8 @@ STREAM_SHAPES = [
     (1, 33, 31, 384, 0, 384, 136),     # N = 136: two channel tiles, the second nearly empty
     (2, 20, 20, 256, 0, 256, 256),     # BN = 128 x 2 tiles (the weights of a 256-wide tile do not leave room for the ring)
     (5, 16, 16, 128, 0, 128, 256),     # BN = 256
+    (2, 20, 20, 512, 0, 512, 520),     # weights too large to stay resident: their chunks travel in the ring (3 channel tiles of 256)
+    (16, 40, 40, 256, 0, 256, 256),    # two resident tiles would stream the pixels twice: one streamed 256-channel tile
 ]
 
 
@@ -615,8 +617,9 @@ def test_stream1x1_matches_generic_kernel_and_exact_integer_conv(shape):
     assert torch.equal(p1.double().sum(0).cpu(), ref) and torch.equal(p0.double().sum(0).cpu(), ref)
 
 
-def test_stream1x1_bias_and_affine_epilogues_match_generic_kernel():
-    B, H, W, Cin, Cout = 2, 19, 21, 128, 72
+@pytest.mark.parametrize("Cin,Cout", [(128, 72), (512, 512)], ids=["resident", "streamed_weights"])
+def test_stream1x1_bias_and_affine_epilogues_match_generic_kernel(Cin, Cout):
+    B, H, W = 2, 19, 21
     g = torch.Generator().manual_seed(5)
     xt = ops.nhwc_empty(B, Cin, H, W, torch.bfloat16, DEV)
     xt.copy_(torch.randn(B, Cin, H, W, generator=g).to(DEV))
