@@ -83,6 +83,12 @@ BENCH_SHAPES = [
     (192, 320, 1, 24, 24, 3),       # Cn % 128 = 64, Cg = 192 (X-model widths)
     (96, 80, 1, 16, 40, 5),         # Cn % 128 = 80 (multiple of 16 only), ragged x tiles
     (1152, 1152, 2, 40, 40, 2),     # groups of 576 -> 576 (M-3D fused layer widths)
+    # narrow body layers: conv3x3_small.hip (all nine taps' weights resident, forward + flipped-tap data gradient)
+    (64, 64, 1, 80, 80, 4),         # the 64 -> 64 Bottleneck convs at 80x80
+    (32, 32, 1, 160, 160, 2),       # 32 -> 32 at 160x160 (64-byte K slabs)
+    (32, 64, 1, 21, 27, 3),         # ragged tiles both ways
+    (64, 24, 1, 24, 40, 1),         # output channels not a multiple of 16
+    (64, 48, 1, 16, 16, 2),         # three output-channel tiles; fewer tiles than partial-sum rows
 ]
 
 

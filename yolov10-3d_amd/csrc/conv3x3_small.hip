@@ -1,0 +1,235 @@
+// 3x3 stride-1 "same" convolution of the NARROW body layers (32 or 64 input channels, at most 64 output channels; bf16): forward and,
+// with flipped taps on dy, the data gradient.  Reference: the Bottleneck 3x3 convs of the first C2f stages (nn/modules/block.py:327-342
+// through conv.py:120-122).
+//
+// These layers fell between the kernels: the resident-halo kernels (conv3x3_wide / conv3x3_tile) compute 128-output-channel tiles
+// - half of the MFMA work is padding at 64 channels, and 32-channel inputs are below their 64-channel K slab - and the generic
+// implicit GEMM gathers every input pixel nine times through L2 (32 -> 32 at 160x160: 82 / 101 us forward / data gradient for
+// 105 MB of tensors).  Here ALL the weights are resident in LDS (9 taps x Cout x Cin: 18-74 KB), a persistent workgroup walks
+// 8 x 16 pixel tiles, the (8 + 2) x (16 + 2) halo of a tile arrives by LDS-DMA (double buffered: the next tile in flight under the
+// MFMAs and the stores of this one; the counted s_waitcnt leaves exactly the stores of a wave outstanding), all nine taps read
+// their shifted windows out of it.  BatchNorm partial sums stay per lane over all tiles of a workgroup and are folded once
+// (row = workgroup index, the remaining rows of the caller's partial buffer are zero-filled).
+#include "common.h"
+
+namespace {
+
+struct SmP {
+  const bf16_t* x;
+  const bf16_t* w;   // [Cout][Ktot], K index = tap * Cin + ci (forward packing, or the dgrad packing of the transposed conv)
+  bf16_t* y;
+  float* part;       // [rows][Cout][2] or null
+  int xsb, xsh, xsw, ysw;
+  int B, H, W, Cin, Cout, Ktot, flip, rows;
+  int nty, ntx, ntiles;
+  unsigned xbytes, ybytes;
+};
+
+template <int N> __device__ __forceinline__ void sm_wvm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef __attribute__((ext_vector_type(2))) unsigned sm_u32x2;
+
+// CB: bytes of one pixel's (or one weight row's) K slab in LDS: 64 (Cin = 32) or 128 (Cin = 64).  Rows of 16-byte chunks, XOR-swizzled
+// so that 16 lanes reading 16 consecutive rows at one chunk index cover all banks: by (row & 7) for 128-byte rows, by ((row >> 2) & 3)
+// for 64-byte rows.
+template <int CB> __device__ __forceinline__ int sm_swz(int row) { return CB == 128 ? (row & 7) : ((row >> 2) & 3); }
+
+template <int CB, int NCT>  // NCT: 16-channel output tiles (Cout <= 16 NCT)
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
+  constexpr int TH = 8, HW = 18, NPIX = (TH + 2) * HW;          // 180 halo pixels
+  constexpr int SPI = 1024 / CB;                                // pixel slots per DMA instruction (8 or 16)
+  constexpr int NINST = (NPIX + SPI - 1) / SPI;                 // 23 / 12
+  constexpr int NI = (NINST + 3) / 4;                           // per wave (the last ones may be dummies into the slack)
+  constexpr int TILE = NI * 4 * 1024;                           // bytes per halo buffer
+  constexpr int KS = CB / 64;                                   // 32-channel MFMA steps per tap
+  constexpr int CPR = CB / 16;                                  // chunks per row
+  constexpr int WB = 9 * NCT * 16 * CB;                         // resident weights [tap][co][CB]
+  constexpr int NST = 2 * NCT;                                  // stores per wave per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;
+  char* sH = smem + WB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwk = gridDim.x, wk = blockIdx.x;
+  const int Cin = CB / 2;
+
+  for (int i = tid; i < 9 * NCT * 16 * CPR; i += 256) {
+    const int c = i % CPR, r = (i / CPR) % (NCT * 16), tap = i / (CPR * NCT * 16);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < p.Cout) v = *(const uint4*)(p.w + (long)r * p.Ktot + (p.flip ? 8 - tap : tap) * Cin + c * 8);
+    *(uint4*)(sW + (tap * NCT * 16 + r) * CB + ((c ^ sm_swz<CB>(r)) << 4)) = v;
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.ybytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+  auto decode = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % p.ntx, t2 = t / p.ntx;
+    x0 = tx * 16;
+    y0 = (t2 % p.nty) * TH;
+    b = t2 / p.nty;
+  };
+  auto issue = [&](int t, int buf) {
+    int b, y0, x0;
+    const bool live = t < p.ntiles;
+    decode(live ? t : 0, b, y0, x0);
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int ii = wave * NI + n;  // uniform
+      const int P = ii * SPI + lane / CPR, cpos = lane % CPR;
+      const int row = P / HW, col = P - row * HW;
+      const int yy = y0 + row - 1, xx = x0 + col - 1;
+      const bool ok = live & (P < NPIX) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+      const unsigned off = (unsigned)(b * p.xsb + yy * p.xsh + xx * p.xsw + ((cpos ^ sm_swz<CB>(P)) << 3)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + buf * TILE + ii * 1024), 16, ok ? off : OOB, 0, 0, 0);
+    }
+  };
+  if (wk < p.ntiles) issue(wk, 0);
+
+  const int lp = lane & 15, lq = lane >> 4;
+  float ssum[NCT][4], ssq[NCT][4];
+#pragma unroll
+  for (int a = 0; a < NCT; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
+  int buf = 0;
+  bool first = true;
+#pragma unroll 1
+  for (int t = wk; t < p.ntiles; t += nwk) {
+    if (first) { sm_wvm<0>(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); first = false; }
+    else sm_wvm<NST>();
+    __builtin_amdgcn_s_barrier();
+    issue(t + nwk, buf ^ 1);
+    int b, y0, x0;
+    decode(t, b, y0, x0);
+    const char* hb = sH + buf * TILE;
+    f32x4_t acc[2][NCT];  // [row of the wave][output-channel tile]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int a = 0; a < NCT; ++a) acc[r][a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tr = tap / 3, tq = tap - tr * 3;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_t fa[NCT], fb[2];
+#pragma unroll
+        for (int a = 0; a < NCT; ++a) {
+          const int r = a * 16 + lp;
+          fa[a] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(sW + (tap * NCT * 16 + r) * CB + (((ks * 4 + lq) ^ sm_swz<CB>(r)) << 4)));
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int P = (wave * 2 + r + tr) * HW + tq + lp;
+          fb[r] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hb + P * CB + (((ks * 4 + lq) ^ sm_swz<CB>(P)) << 4)));
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int a = 0; a < NCT; ++a) acc[r][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[r], acc[r][a], 0, 0, 0);
+      }
+    }
+    // lane: pixel (y0 + 2 wave + r, x0 + lp), output channels 16 a + 4 lq .. + 3
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int yy = y0 + wave * 2 + r, xx = x0 + lp;
+      const bool inb = (yy < p.H) & (xx < p.W);
+      const unsigned pix = (unsigned)((b * p.H + yy) * p.W + xx) * (unsigned)p.ysw;
+#pragma unroll
+      for (int a = 0; a < NCT; ++a) {
+        const int co = a * 16 + 4 * lq;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = bf2f(f2bf(acc[r][a][j]));
+          if (inb) { ssum[a][j] += v[j]; ssq[a][j] += v[j] * v[j]; }
+        }
+        const sm_u32x2 u = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+        __builtin_amdgcn_raw_buffer_store_b64(u, ry, inb & (co < p.Cout) ? (pix + co) * 2u : OOB, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+  sm_wvm<0>();
+  if (p.part) {
+    __syncthreads();
+    float* red = (float*)sH;  // [4 waves][NCT * 16][2]
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = wave_xor_sum16(ssum[a][j]), q = wave_xor_sum16(ssq[a][j]);
+        if (lp == 0) {
+          red[(wave * NCT * 16 + a * 16 + 4 * lq + j) * 2] = s;
+          red[(wave * NCT * 16 + a * 16 + 4 * lq + j) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < p.Cout) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s += red[(w * NCT * 16 + tid) * 2]; q += red[(w * NCT * 16 + tid) * 2 + 1]; }
+      float* dst = p.part + ((long)wk * p.Cout + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+    // rows nobody owns: zeros (the finalize pass sums every row of the caller's buffer)
+    for (int row = wk + nwk; row < p.rows; row += nwk)
+      for (int c = tid; c < p.Cout; c += 256) *(float2*)(p.part + ((long)row * p.Cout + c) * 2) = make_float2(0.f, 0.f);
+  }
+}
+
+template <int CB, int NCT>
+void sm_launch(const SmP& p, int grid, hipStream_t st) {
+  constexpr int SPI = 1024 / CB, NINST = (180 + SPI - 1) / SPI, NI = (NINST + 3) / 4;
+  const size_t lds = (size_t)9 * NCT * 16 * CB + 2 * (size_t)NI * 4 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT>), dim3(grid), dim3(256), lds, st, p);
+}
+
+}  // namespace
+
+extern "C" int y3d_get_stream1x1(void);
+
+int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int rows) {
+  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || (Cin != 32 && Cin != 64) || Cout > 64 || Cout < 8 || Cout % 4 != 0) return 0;
+  if (H < 4 || W < 8 || rows < 1) return 0;
+  return 1;
+}
+
+int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
+                             long ysw, float* part, int rows, int flip, void* stream) {
+  Y3D_CHECK(((uintptr_t)x & 15) == 0 && xsb % 8 == 0 && xsh % 8 == 0 && xsw % 8 == 0 && ((uintptr_t)w & 15) == 0 && Ktot % 8 == 0 &&
+                ((uintptr_t)y & 7) == 0 && ysw % 4 == 0, "conv3x3_small: operand alignment");
+  const long xext = ((long)(B - 1) * xsb + (long)(H - 1) * xsh + (long)(W - 1) * xsw + Cin) * 2;
+  const long yext = (((long)B * H * W - 1) * ysw + Cout) * 2;
+  Y3D_CHECK(xext < (1L << 32) - 64 && yext < (1L << 32) - 64 && (long)B * xsb < (1L << 31) && (long)B * H * W * ysw < (1L << 31),
+            "conv3x3_small: tensors beyond 32-bit byte offsets");
+  SmP p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.part = part;
+  p.xsb = (int)xsb; p.xsh = (int)xsh; p.xsw = (int)xsw; p.ysw = (int)ysw;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ktot = Ktot; p.flip = flip; p.rows = rows;
+  p.nty = cdiv(H, 8); p.ntx = cdiv(W, 16); p.ntiles = B * p.nty * p.ntx;
+  p.xbytes = (unsigned)xext; p.ybytes = (unsigned)yext;
+  const int nct = cdiv(Cout, 16);
+  const int cb = Cin * 2;
+  const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
+  int grid = 256 * (lds <= 80 * 1024 ? 2 : 1);
+  if (grid > p.ntiles) grid = p.ntiles;
+  if (part && grid > rows) grid = rows;
+  hipStream_t st = (hipStream_t)stream;
+#define SM_GO(CB)                                                   \
+  switch (nct) {                                                    \
+    case 1: sm_launch<CB, 1>(p, grid, st); break;                   \
+    case 2: sm_launch<CB, 2>(p, grid, st); break;                   \
+    case 3: sm_launch<CB, 3>(p, grid, st); break;                   \
+    default: sm_launch<CB, 4>(p, grid, st); break;                  \
+  }
+  if (cb == 128) { SM_GO(128) } else { SM_GO(64) }
+#undef SM_GO
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}

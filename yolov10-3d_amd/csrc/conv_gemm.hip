@@ -721,6 +721,11 @@ int y3d_wgrad1x1_stream_launch(const void* x, long xsw, const void* dy, long dsw
 int y3d_conv3x3s2_dgrad_ok(int dtype, int B, int Ho, int Wo, int H, int W, int Cout, int Cin, long dsw, long xsw);
 int y3d_conv3x3s2_dgrad_launch(const void* dy, long dsw, int B, int Ho, int Wo, int Cout, const void* w_packed_dgrad, int Kpad, void* dx, long xsw,
                                int H, int W, int Cin, void* stream);
+// conv3x3_small.hip
+int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int rows);
+int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
+                             long ysw, float* part, int rows, int flip, void* stream);
+extern "C" int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
 static inline bool dense_pixels(int B, int H, int W, long sb, long sh, long sw) {
   return (H == 1 || sh == (long)W * sw) && (B == 1 || sb == (long)H * W * sw);
 }
@@ -828,6 +833,11 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
   if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, H, W, xsb, xsh, xsw) &&
       y3d_conv1x1_stream_ok(dtype, p.M, Cin, Cout, xsw))
     return y3d_conv1x1_stream_launch(x, xsw, w_packed, p.Kpad, bias, scale, shift, act, y, ysw, stat_partials, p.M, Cin, Cout, stream);
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && !bias && !scale) {
+    const int rows = stat_partials ? y3d_conv2d_stat_rows(dtype, B, H, W, Cin, Cout, groups, kh, kw, stride, pad) : 1;
+    if (y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, rows))
+      return y3d_conv3x3_small_launch(x, xsb, xsh, xsw, B, H, W, Cin, Cout, w_packed, p.Ktot, y, ysw, stat_partials, rows, 0, stream);
+  }
   if (!bias && g_tile_kernels) {
     int th = y3d_tile_height(dtype, B, H, W, p.Cg, p.Cn, groups, kh, kw, stride, pad);
     if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, scale, shift, act, stream);
@@ -872,6 +882,8 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
       y3d_conv1x1_stream_ok(dtype, p.M, Cout, Cin, dsw))
     return y3d_conv1x1_stream_launch(dy, dsw, w_packed_dgrad, p.Kpad, nullptr, nullptr, nullptr, 0, dx, xsw, nullptr, p.M, Cout, Cin, stream);
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && Ho == H && Wo == W && y3d_conv3x3_small_ok(dtype, B, H, W, Cout, Cin, 1))
+    return y3d_conv3x3_small_launch(dy, dsb, dsh, dsw, B, H, W, Cout, Cin, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, 1, stream);
   if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
       y3d_conv3x3s2_dgrad_ok(dtype, B, Ho, Wo, H, W, Cout, Cin, dsw, xsw))
     return y3d_conv3x3s2_dgrad_launch(dy, dsw, B, Ho, Wo, Cout, w_packed_dgrad, p.Kpad, dx, xsw, H, W, Cin, stream);
