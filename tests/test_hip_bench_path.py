@@ -586,6 +586,8 @@ STREAM_SHAPES = [
     (5, 16, 16, 128, 0, 128, 256),     # BN = 256
     (2, 20, 20, 512, 0, 512, 520),     # weights too large to stay resident: their chunks travel in the ring (3 channel tiles of 256)
     (16, 40, 40, 256, 0, 256, 256),    # two resident tiles would stream the pixels twice: one streamed 256-channel tile
+    (2, 24, 24, 48, 0, 48, 96),        # K = 48 (M-model widths): the second MFMA step of the only K chunk is half zeros
+    (2, 20, 20, 336, 8, 144, 288),     # K = 144 = 2 chunks + 16, a slice view at channel offset 8, streamed weights (N > 256)
 ]
 
 

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
     }
     const char* tA = sA + c_slot * STAGE + (wp * (BM / WP)) * 128;
     const char* tW = WRES ? sW + (c_kc * BN + wc * (BN / WC)) * 128 : sA + c_slot * STAGE + (BM + wc * (BN / WC)) * 128;
-    const int nks = p.K - c_kc * 64 >= 64 ? 2 : 1;
+    const int nks = p.K - c_kc * 64 > 32 ? 2 : 1;  // K is a multiple of 8: chunks past K were zero-filled by the range check
     for (int ks = 0; ks < nks; ++ks) {
       bf16x8_t fb[TP], fa[TC];
 #pragma unroll
@@ -327,7 +327,7 @@ extern "C" int y3d_set_stream1x1(int enable) {
 // Does the streaming kernel take this GEMM?  (bf16, K a multiple of 32, dense pixel rows, 32-bit byte offsets, at most `max_nnt`
 // channel tiles: every extra channel tile streams the pixel operand again)
 int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw) {
-  if (!g_stream1x1 || dtype != Y3D_BF16 || K % 32 != 0 || K < 32 || N < 8 || N % 4 != 0 || M < 128) return 0;
+  if (!g_stream1x1 || dtype != Y3D_BF16 || K % 8 != 0 || K < 32 || N < 8 || N % 4 != 0 || M < 128) return 0;
   if ((M * xsw + K) * 2 >= (1L << 32) - 64 || M * N * 2 >= (1L << 31)) return 0;
   PwPlan pl;
   if (!pw_plan((int)M, K, N, &pl)) return 0;
