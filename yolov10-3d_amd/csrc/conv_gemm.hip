@@ -726,6 +726,11 @@ int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int 
 int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
                              long ysw, float* part, int rows, int flip, void* stream);
 extern "C" int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
+// wgrad3x3_small.hip
+int y3d_wgrad3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout);
+int y3d_wgrad3x3_small_splits(int B, int H, int W);
+int y3d_wgrad3x3_small_launch(const void* x, long xsb, long xsh, long xsw, const void* dy, long dsw, int B, int H, int W, int Cin, int Cout,
+                              float* slab, int nsplit, void* stream);
 static inline bool dense_pixels(int B, int H, int W, long sb, long sh, long sw) {
   return (H == 1 || sh == (long)W * sw) && (B == 1 || sb == (long)H * W * sw);
 }
@@ -746,6 +751,8 @@ int y3d_set_tile_kernels(int enable) {
 int y3d_conv_stat_blocks(int B, int Ho, int Wo) { return cdiv((long)B * Ho * Wo, 128); }
 
 int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && y3d_wgrad3x3_small_ok(dtype, B, H, W, Cin, Cout))
+    return y3d_wgrad3x3_small_splits(B, H, W);
   int th = (g_tile_kernels && groups > 0) ? y3d_wgrad_tile_height(dtype, H, W, Cin / groups, Cout / groups, kh, kw, stride, pad) : 0;
   if (th) return y3d_wgrad_tile_splits(th, B, H, W, Cin / groups, Cout / groups, groups);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
@@ -939,6 +946,13 @@ int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, in
   p.Ktot = kh * kw * p.Cg; p.M = B * Ho * Wo; p.nsplit = nsplit;
   p.chunk_px = cdiv(cdiv(p.M, nsplit), bpk) * bpk;
   hipStream_t st = (hipStream_t)stream;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && Cin_real == Cin && y3d_wgrad3x3_small_ok(dtype, B, H, W, Cin, Cout)) {
+    int rc = y3d_wgrad3x3_small_launch(x, xsb, xsh, xsw, dy, dsw, B, H, W, Cin, Cout, slab, nsplit, stream);
+    if (rc) return rc;
+    launch_wgrad_reduce(slab, grad_oihw, nsplit, Cout, 9, Cin, Cin, accumulate, st);
+    Y3D_LAUNCH_CHECK();
+    return Y3D_OK;
+  }
   {
     int th = g_tile_kernels ? y3d_wgrad_tile_height(dtype, H, W, p.Cg, p.Cn, kh, kw, stride, pad) : 0;
     if (th && Cin_real == Cin) {
