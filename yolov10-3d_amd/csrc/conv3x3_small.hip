@@ -67,19 +67,29 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
     y0 = (t2 % p.nty) * TH;
     b = t2 / p.nty;
   };
+  // DMA plan of this lane, computed once: per instruction its halo pixel (row, column) and its element offset relative to the tile's
+  // origin pixel (the chunk -> pixel maps cost more VALU time per tile than the bounds tests that remain)
+  int p_off[NI], p_rc[NI];  // (row << 8) | column, row 255 = never valid
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int ii = wave * NI + n;
+    const int P = ii * SPI + lane / CPR, cpos = lane % CPR;
+    const int row = P / HW, col = P - row * HW;
+    p_off[n] = (row - 1) * p.xsh + (col - 1) * p.xsw + ((cpos ^ sm_swz<CB>(P)) << 3);
+    p_rc[n] = ((P < NPIX ? row : 255) << 8) | col;
+  }
   auto issue = [&](int t, int buf) {
     int b, y0, x0;
     const bool live = t < p.ntiles;
     decode(live ? t : 0, b, y0, x0);
+    const int base = b * p.xsb + y0 * p.xsh + x0 * p.xsw;
+    const int hlim = live ? p.H : 0;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
-      const int ii = wave * NI + n;  // uniform
-      const int P = ii * SPI + lane / CPR, cpos = lane % CPR;
-      const int row = P / HW, col = P - row * HW;
-      const int yy = y0 + row - 1, xx = x0 + col - 1;
-      const bool ok = live & (P < NPIX) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
-      const unsigned off = (unsigned)(b * p.xsb + yy * p.xsh + xx * p.xsw + ((cpos ^ sm_swz<CB>(P)) << 3)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + buf * TILE + ii * 1024), 16, ok ? off : OOB, 0, 0, 0);
+      const int r = p_rc[n] >> 8, c = p_rc[n] & 255;
+      const bool ok = ((unsigned)(y0 - 1 + r) < (unsigned)hlim) & ((unsigned)(x0 - 1 + c) < (unsigned)p.W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + buf * TILE + (wave * NI + n) * 1024), 16,
+                                               ok ? (unsigned)(base + p_off[n]) * 2u : OOB, 0, 0, 0);
     }
   };
   if (wk < p.ntiles) issue(wk, 0);

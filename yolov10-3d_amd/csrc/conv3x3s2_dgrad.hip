@@ -63,22 +63,32 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
     hy0 = (t2 % p.nty) * TH;
     b = t2 / p.nty;
   };
-  // DMA instruction ii (0 .. 20 NSLAB - 1): slab ii / 20, slots 8 (ii % 20) .. + 7; lane l: slot + (l >> 3), chunk (l & 7) ^ (l >> 3)
+  // DMA instruction ii (0 .. 20 NSLAB - 1): slab ii / 20, slots 8 (ii % 20) .. + 7; lane l: slot + (l >> 3), chunk (l & 7) ^ (l >> 3).
+  // The lane's halo pixel and element offset per instruction are computed once (per tile: two compares, an add, a select each).
+  int p_off[NI], p_rc[NI];  // (row << 8) | column, row 255 = never valid
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int ii = wave * NI + n;
+    const int sl = ii / 20, s8 = ii - sl * 20;
+    const int P = s8 * 8 + (lane >> 3);
+    const int row = P / HW, col = P - row * HW;
+    p_off[n] = (row * p.Wo + col) * p.dsw + sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3);
+    p_rc[n] = ((P < (TH + 1) * HW ? row : 255) << 8) | col;
+  }
   auto issue = [&](int t, int buf) {
     int b, hy0, wx0;
     const bool live = t < p.ntiles;
     decode(live ? t : 0, b, hy0, wx0);
+    const int base = ((b * p.Ho + hy0) * p.Wo + wx0) * p.dsw;
+    const int hlim = live ? p.Ho : 0;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int ii = wave * NI + n;  // uniform
       const int sl = ii / 20, s8 = ii - sl * 20;
-      const int P = s8 * 8 + (lane >> 3);
-      const int row = P / HW, col = P - row * HW;
-      const int hy = hy0 + row, wx = wx0 + col;
-      const bool ok = live & (P < (TH + 1) * HW) & (hy < p.Ho) & (wx < p.Wo);
-      const unsigned off = (unsigned)(((b * p.Ho + hy) * p.Wo + wx) * p.dsw + sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3)) * 2u;
+      const int r = p_rc[n] >> 8, c = p_rc[n] & 255;
+      const bool ok = (hy0 + r < hlim) & (wx0 + c < p.Wo);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(sH + buf * TILE + (sl * SLOTS + s8 * 8) * 128), 16,
-                                               ok ? off : OOB, 0, 0, 0);
+                                               ok ? (unsigned)(base + p_off[n]) * 2u : OOB, 0, 0, 0);
     }
   };
   issue(wk, 0);
