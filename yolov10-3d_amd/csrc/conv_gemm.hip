@@ -514,10 +514,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-// slab[split][co][tap][ci]  ->  grad OIHW [co][ci][tap]  (accumulate optional).  SL split-lanes per element: a narrow layer has
-// few elements and many splits, so the split loop is shared by SL threads and folded through LDS.
+// slab[split][co][tap][ci]  ->  grad OIHW [co][ci][tap]  (accumulate optional).  SL split-lanes per element group: a narrow layer has
+// few elements and many splits, so the split loop is shared by SL threads and folded through LDS.  A thread owns FOUR consecutive
+// elements (one float4 per slab: 512-byte runs per slab row and wave instead of 128 - the fold reads nsplit x n floats and was at
+// 2.7 TB/s with scalar loads); n is a multiple of 4 because Cg is a multiple of the 16-byte chunk.
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int Ctot,
+                                                           int taps, int Cg, int Cg_real, int accumulate) {
+  constexpr int GPB = 256 / SL;  // float4 groups per block
+  __shared__ float4 sh[SL][GPB];
+  const int e = threadIdx.x % GPB, sl = threadIdx.x / GPB;
+  const long idx = ((long)blockIdx.x * GPB + e) * 4;
+  const long n = (long)Ctot * taps * Cg;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < n) {
+    // four slabs in flight per lane (the partial sums keep a fixed order: bitwise reproducible)
+    float4 s0 = s, s1 = s, s2 = s, s3 = s;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    int k = sl;
+    for (; k + 3 * SL < nsplit; k += 4 * SL) {
+      const float4 v0 = *(const float4*)(slab + (long)k * n + idx), v1 = *(const float4*)(slab + (long)(k + SL) * n + idx);
+      const float4 v2 = *(const float4*)(slab + (long)(k + 2 * SL) * n + idx), v3 = *(const float4*)(slab + (long)(k + 3 * SL) * n + idx);
+      add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
+    }
+    for (; k < nsplit; k += SL) add(s0, *(const float4*)(slab + (long)k * n + idx));
+    s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
+    s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
+  }
+  if (SL > 1) {
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl != 0) return;
+#pragma unroll
+    for (int j = 1; j < SL; ++j) { const float4 v = sh[j][e]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  }
+  if (idx >= n) return;
+  const int ci = (int)(idx % Cg);  // the four elements share (co, tap): Cg % 4 == 0
+  const int tap = (int)((idx / Cg) % taps);
+  const int co = (int)(idx / ((long)Cg * taps));
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (ci + j >= Cg_real) break;  // channel padding
+    const long o = ((long)co * Cg_real + ci + j) * taps + tap;
+    grad[o] = accumulate ? grad[o] + v[j] : v[j];
+  }
+}
+
+// one element per thread: the form for few, large slabs (head layers: nsplit < 8, 2.4 M elements) - there the transposing
+// 4-byte writes dominate and four of them per thread were slower (49 -> 60 us)
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int Ctot,
                                                            int taps, int Cg, int Cg_real, int accumulate) {
   constexpr int EPB = 256 / SL;  // elements per block
   __shared__ float sh[SL][EPB];
@@ -556,11 +603,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 inline void launch_wgrad_reduce(const float* slab, float* grad, int nsplit, int Ctot, int taps, int Cg, int Cg_real, int accumulate, hipStream_t st) {
   long n = (long)Ctot * taps * Cg;
-  // split lanes per element: enough loads in flight for the slab stream (nsplit x n floats) whatever the layer's shape
-  if (n <= 65536 && nsplit >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 16)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
-  else if (n <= 1048576 && nsplit >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(cdiv(n, 32)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
-  else if (nsplit >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(cdiv(n, 128)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  long ng = (n + 3) / 4;  // float4 groups
+  // split lanes per element group: enough loads in flight for the slab stream (nsplit x n floats) whatever the layer's shape
+  if (n <= 65536 && nsplit >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(ng, 16)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  else if (n <= 1048576 && nsplit >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(cdiv(ng, 32)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  else if (nsplit >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(cdiv(ng, 128)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
+  else hipLaunchKernelGGL(wgrad_reduce_scalar_kernel<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, grad, nsplit, Ctot, taps, Cg, Cg_real, accumulate);
 }
 
 // OIHW fp32 -> packed [Cout][taps][Cg_pad] (forward) in T, row pitch Kpad
