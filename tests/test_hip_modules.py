@@ -623,14 +623,16 @@ def test_tile_kernels_agree_with_generic_kernels(case):
         check(a, b, tol, f"tile vs generic {what}")
 
 
+@pytest.mark.parametrize("dims", [(32, 64), (36, 72)], ids=["kd32_hd64", "kd36_hd72"])
 @pytest.mark.parametrize("shape", [(2, 20, 20, 2), (1, 7, 11, 1), (1, 40, 40, 4)])
-def test_attention_mfma_vs_valu(shape):
-    """bf16 PSA attention: MFMA kernel (S^T = K Q^T, O^T = V^T P^T on the matrix cores) vs the fp32-VALU kernel on the same qkv"""
+def test_attention_mfma_vs_valu(shape, dims):
+    """bf16 PSA attention: MFMA kernel (S^T = K Q^T, O^T = V^T P^T on the matrix cores) vs the fp32-VALU kernel on the same qkv;
+    kd = 36 / hd = 72 (the M widths: head blocks at 8-byte offsets, fragments zero-padded past the head dims)"""
     B, H, W, nh = shape
     y3d.set_compute_dtype(torch.bfloat16)
     L = y3d.lib()
     torch.manual_seed(2)
-    kd, hd = 32, 64
+    kd, hd = dims
     qkv = y3d.ops.to_nhwc(torch.randn(B, nh * (2 * kd + hd), H, W, device=DEV), torch.bfloat16)
     res = {}
     for enable in (1, 0):
@@ -649,15 +651,16 @@ def test_attention_mfma_vs_valu(shape):
 
 
 # N = 1600 and N = 621: the LDS images of the MFMA backward hold 1024 keys / 512 queries, longer sequences walk them in passes
+@pytest.mark.parametrize("dims", [(32, 64), (36, 72)], ids=["kd32_hd64", "kd36_hd72"])
 @pytest.mark.parametrize("shape", [(2, 20, 20, 2), (1, 7, 11, 1), (1, 40, 40, 4), (3, 20, 20, 2), (1, 23, 27, 2)])
-def test_attention_backward_mfma_vs_valu_and_autograd(shape):
+def test_attention_backward_mfma_vs_valu_and_autograd(shape, dims):
     """bf16 PSA attention backward: the MFMA kernels (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS) vs the fp32-VALU kernels and vs
     torch autograd on plain fp32 math; the second output (v, consumed by the positional-encoding branch) feeds dv_extra"""
     B, H, W, nh = shape
     y3d.set_compute_dtype(torch.bfloat16)
     L = y3d.lib()
     torch.manual_seed(4)
-    kd, hd = 32, 64
+    kd, hd = dims
     x = torch.randn(B, nh * (2 * kd + hd), H, W, device=DEV)
     r1 = torch.randn(B, nh * hd, H, W, device=DEV)
     r2 = torch.randn(B, nh * hd, H, W, device=DEV)

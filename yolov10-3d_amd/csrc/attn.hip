@@ -203,35 +203,84 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(AttnBP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// MFMA forward (bf16, kd = 32, hd = 64): S^T = K Q^T and O^T = V^T P^T on the matrix cores.
+// MFMA forward (bf16; kd = 32 / hd = 64, and kd = 36 / hd = 72 of the M widths): S^T = K Q^T and O^T = V^T P^T on the matrix cores.
 // One wave owns 16 queries.  S^T tiles come out of `mfma(A = K rows, B = Q rows)` with the query on the lane and four keys in
 // the registers - exactly the B-operand layout the second product needs (`An accumulator tile as the next MFMA's operand`), so
 // P never leaves the registers.  The reduction index of O^T = V^T P^T is the key; its MFMA-k <-> key assignment is permuted
 // (k = 8g+j <-> key 32*ks + 16*(j>>2) + 4g + (j&3)) to match the S^T accumulator layout, and V^T fragments are fetched from a
 // swizzled LDS image of V with the transposed read.  Softmax is two-pass (row max first: QK^T is one MFMA per 16 x 16 tile, so
 // recomputing it is cheaper than rescaling O), fp32 throughout.
+// Head dims that are not multiples of 32 / 16 are zero-padded IN THE FRAGMENTS (kd = 36: a second K step with four live elements;
+// hd = 72: a fifth, half-empty output tile and a third K step for the products that contract over hd).  The q | k | v blocks of a
+// head then start at 8-byte, not 16-byte, offsets (k at element 36): global 16-byte loads only need dword alignment; the element
+// mask is applied per 8-element chunk (`ld8m`).
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int KC = 512;  // keys per LDS chunk of V (64 KB)
+constexpr int KC = 512;  // keys per LDS chunk of V
 
+__device__ __forceinline__ bf16x8_t ld8(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
+__device__ __forceinline__ bf16x8_t zero8() { return (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
+// elements e0 .. e0 + 7 of a row whose live length is lim (a multiple of 4): zeros past lim
+__device__ __forceinline__ bf16x8_t ld8m(const bf16_t* row, int e0, int lim) {
+  if (e0 + 8 <= lim) return ld8(row + e0);
+  if (e0 >= lim) return zero8();
+  const uint2 u = *(const uint2*)(row + e0);  // four live elements
+  return __builtin_bit_cast(bf16x8_t, make_uint4(u.x, u.y, 0u, 0u));
+}
+__device__ __forceinline__ uint4 ld8mu(const bf16_t* row, int e0, int lim) { return __builtin_bit_cast(uint4, ld8m(row, e0, lim)); }
+
+// transposed A fragment out of an LDS image with ROWB-byte rows whose 32-byte pieces are XOR-swizzled by the row:
+// element block [rows 32*ks + 16*hi + 4*grp + 0..3][columns col0 + 16-wide tile], lane li = 4*qq + pp4
+template <int ROWB>
+__device__ __forceinline__ int img_swz(int P) { return ((P >> (ROWB == 128 ? 1 : 0)) & (ROWB / 32 - 1)) << 1; }
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t frag_t(const char* img, int ks, int col0, int grp, int qq, int pp4) {
+  s16x4_t v[2];
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+    const int P = ks * 32 + 16 * hi + 4 * grp + qq;
+    const int cch = (col0 >> 3) + (pp4 >> 1);  // 16-byte chunk of the row
+    const char* a = img + P * ROWB + ((cch ^ img_swz<ROWB>(P)) << 4) + (pp4 & 1) * 8;
+    v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
+  }
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int KD, int HD>
+struct AttnDims {
+  static constexpr int KSK = (KD + 31) / 32, NTK = (KD + 15) / 16;   // K steps / 16-wide tiles over the key dimension
+  static constexpr int KSH = (HD + 31) / 32, NTH = (HD + 15) / 16;   // ... over the head dimension
+  static constexpr int VROW = HD <= 64 ? 128 : 256;                  // V image row (forward)
+  static constexpr int KROW = 128;                                   // K image row (bwd_q): up to 64 elements
+  static constexpr int HDI = KSH * 32, KDI = NTK * 16 <= 32 ? 32 : 64;
+  static constexpr int IROW = (HDI + KDI) * 2 <= 256 ? 256 : 512;    // dO | Q image row (bwd_kv)
+};
+
+template <int KD, int HD>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
   typedef bf16_t T;
-  constexpr int KD = 32, HD = 64;
-  extern __shared__ __attribute__((aligned(16))) char sV[];  // [KC][128 B], 16-byte chunks XOR-swizzled by ((row>>1)&3)<<1
+  typedef AttnDims<KD, HD> D;
+  constexpr int VROW = D::VROW, CPV = VROW / 16;
+  extern __shared__ __attribute__((aligned(16))) char sV[];  // [KC][VROW], 16-byte chunks XOR-swizzled by the row (img_swz)
   const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int hoff = h * (2 * KD + HD);
   const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
-  // Q fragment (B operand): query q0 + li, elements 8*grp .. 8*grp+7
-  bf16x8_t fq = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-  if (q0 + li < p.N) fq = __builtin_bit_cast(bf16x8_t, *(const uint4*)(base + (long)(q0 + li) * p.qsw + 8 * grp));
+  // Q fragments (B operand): query q0 + li, elements 32 k2 + 8 grp .. + 7
+  bf16x8_t fq[D::KSK];
+#pragma unroll
+  for (int k2 = 0; k2 < D::KSK; ++k2) fq[k2] = q0 + li < p.N ? ld8m(base + (long)(q0 + li) * p.qsw, 32 * k2 + 8 * grp, KD) : zero8();
   const int ntile = (p.N + 15) / 16;
   auto score_tile = [&](int t) -> f32x4_t {  // S^T tile: reg r <-> key 16t + 4*grp + r, column <-> query q0 + li
-    bf16x8_t fk = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-    int key = 16 * t + li;
-    if (key < p.N) fk = __builtin_bit_cast(bf16x8_t, *(const uint4*)(base + (long)key * p.qsw + KD + 8 * grp));
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const int key = 16 * t + li;
+    f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k2 = 0; k2 < D::KSK; ++k2) {
+      const bf16x8_t fk = key < p.N ? ld8m(base + (long)key * p.qsw + KD, 32 * k2 + 8 * grp, KD) : zero8();
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[k2], s, 0, 0, 0);
+    }
+    return s;
   };
   // pass 1: row maxima
   float m = -INFINITY;
@@ -245,18 +294,19 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
   m = fmaxf(m, __shfl_xor(m, 32));
   const float ms = m * p.scale;
   // pass 2
-  f32x4_t o[4];
+  f32x4_t o[D::NTH];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int dt = 0; dt < D::NTH; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float l = 0.f;
   for (int c0 = 0; c0 < p.N; c0 += KC) {
     const int nk = min(KC, p.N - c0);
     const int nk32 = (nk + 31) & ~31;
     __syncthreads();
-    for (int id = tid; id < nk32 * 8; id += 256) {
-      int P = id >> 3, s8 = id & 7;
+    for (int id = tid; id < nk32 * CPV; id += 256) {
+      const int P = id / CPV, s8 = id % CPV;
+      const int src = s8 ^ img_swz<VROW>(P);  // position s8 of the row holds source chunk src
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (P < nk) v = *(const uint4*)(base + (long)(c0 + P) * p.qsw + 2 * KD + ((s8 ^ (((P >> 1) & 3) << 1)) * 8));
+      if (P < nk) v = ld8mu(base + (long)(c0 + P) * p.qsw + 2 * KD, src * 8, HD);
       *(uint4*)(sV + id * 16) = v;
     }
     __syncthreads();
@@ -277,18 +327,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) fp[j] = (__bf16)pv[j];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int cch = (dt * 16 >> 3) + (pp4 >> 1);
-        s16x4_t v[2];
-#pragma unroll
-        for (int hi = 0; hi < 2; ++hi) {
-          const int P = ks * 32 + 16 * hi + 4 * grp + qq;
-          const char* a = sV + P * 128 + ((cch ^ (((P >> 1) & 3) << 1)) << 4) + (pp4 & 1) * 8;
-          v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
-        }
-        bf16x8_t fv = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp, o[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < D::NTH; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<VROW>(sV, ks, dt * 16, grp, qq, pp4), fp, o[dt], 0, 0, 0);
     }
   }
   l += __shfl_xor(l, 16);
@@ -297,7 +336,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
     const float inv = 1.f / l;
     T* dst = (T*)p.out + ((long)b * p.N + q0 + li) * p.osw + h * HD;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < D::NTH; ++dt) {
+      if (dt * 16 + 4 * grp >= HD) continue;
       uint2 u;
       u.x = (unsigned)f2bf(o[dt][0] * inv) | ((unsigned)f2bf(o[dt][1] * inv) << 16);
       u.y = (unsigned)f2bf(o[dt][2] * inv) | ((unsigned)f2bf(o[dt][3] * inv) << 16);
@@ -308,38 +348,21 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// MFMA backward (bf16, kd = 32, hd = 64), same register choreography as the forward:
+// MFMA backward (bf16), same register choreography as the forward:
 //   attn_bwd_q_mfma : one wave owns 16 queries (the lane's column).  Per 32 keys: S^T = K Q^T and dP^T = V dO^T tiles come out
 //     with four keys in the registers, dS^T = P^T o (dP^T - delta) becomes the B operand of dQ^T += K^T dS^T as it is; the K^T
 //     fragments come from a swizzled LDS image of K with the transposed read.  Also writes delta_i = dO_i . O_i.
 //   attn_bwd_kv_mfma: one wave owns 16 keys.  Per 32 queries: S = Q K^T and dP = dO V^T tiles with four queries in the registers;
 //     P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS, whose A fragments come from an LDS image
-//     [query][dO (64) | Q (32)] with the transposed read.
+//     [query][dO | Q] with the transposed read.
 // The reduction index <-> MFMA-k assignment is permuted as in the forward (k = 8g+j <-> row 32*ks + 16*(j>>2) + 4g + (j&3)).
 // ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8_t ld8(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
-__device__ __forceinline__ bf16x8_t zero8() { return (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
-
-// transposed A fragment out of an LDS image with ROWB-byte rows whose 32-byte pieces are XOR-swizzled by the row:
-// element block [rows 32*ks + 16*hi + 4*grp + 0..3][columns col0 + 16-wide tile], lane li = 4*qq + pp4
-template <int ROWB>
-__device__ __forceinline__ bf16x8_t frag_t(const char* img, int ks, int col0, int grp, int qq, int pp4) {
-  constexpr int SW = ROWB / 32 - 1;  // 32-byte pieces per row - 1 (3 for 128-byte rows, 7 for 256-byte rows)
-  s16x4_t v[2];
-#pragma unroll
-  for (int hi = 0; hi < 2; ++hi) {
-    const int P = ks * 32 + 16 * hi + 4 * grp + qq;
-    const int cch = (col0 >> 3) + (pp4 >> 1);  // 16-byte chunk of the row
-    const char* a = img + P * ROWB + ((cch ^ (((P >> (ROWB == 128 ? 1 : 0)) & SW) << 1)) << 4) + (pp4 & 1) * 8;
-    v[hi] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
-  }
-  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
+template <int KD, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
   typedef bf16_t T;
-  constexpr int KD = 32, HD = 64;
-  extern __shared__ __attribute__((aligned(16))) char sK[];  // [N32][128 B]: K in the first 64 bytes of a row (V-image geometry)
+  typedef AttnDims<KD, HD> D;
+  constexpr int KROW = D::KROW, NCK = D::NTK * 2;  // chunks of a key's K image row that the dQ tiles read (zero-padded past kd)
+  extern __shared__ __attribute__((aligned(16))) char sK[];  // [chunk keys][128 B]
   const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
@@ -348,17 +371,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
   const T* base = (const T*)p.qkv + (long)b * p.N * p.qsw + hoff;
   const int n32 = (p.N + 31) & ~31;
   const bool qv = q0 + li < p.N;
-  const bf16x8_t fq = qv ? ld8(base + (long)(q0 + li) * p.qsw + 8 * grp) : zero8();
-  bf16x8_t fdo[2];
+  bf16x8_t fq[D::KSK], fdo[D::KSH];
+#pragma unroll
+  for (int k2 = 0; k2 < D::KSK; ++k2) fq[k2] = qv ? ld8m(base + (long)(q0 + li) * p.qsw, 32 * k2 + 8 * grp, KD) : zero8();
   float delta = 0.f, lse = 0.f;
   {
     const T* dp = (const T*)p.dout + ((long)b * p.N + q0 + li) * p.dsw + h * HD;
     const T* op = (const T*)p.out + ((long)b * p.N + q0 + li) * p.osw + h * HD;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      fdo[k2] = qv ? ld8(dp + 32 * k2 + 8 * grp) : zero8();
+    for (int k2 = 0; k2 < D::KSH; ++k2) {
+      fdo[k2] = qv ? ld8m(dp, 32 * k2 + 8 * grp, HD) : zero8();
       if (qv) {
-        const bf16x8_t fo = ld8(op + 32 * k2 + 8 * grp);
+        const bf16x8_t fo = ld8m(op, 32 * k2 + 8 * grp, HD);
 #pragma unroll
         for (int j = 0; j < 8; ++j) delta += (float)fdo[k2][j] * (float)fo[j];
       }
@@ -370,15 +394,17 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
       if (grp == 0) p.delta[((long)b * p.nh + h) * p.N + q0 + li] = delta;
     }
   }
-  f32x4_t dq[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+  f32x4_t dq[D::NTK];
+#pragma unroll
+  for (int dt = 0; dt < D::NTK; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int cb = 0; cb < n32; cb += p.chunk) {  // the K image holds p.chunk keys: long sequences (hi-res maps) walk it in passes
   const int cn = min(p.chunk, n32 - cb);
   if (cb) __syncthreads();  // the previous pass's readers are done with the image
-  for (int id = tid; id < cn * 4; id += 256) {  // K image: 4 chunks of 16 B per key
-    const int Pl = id >> 2, s4 = id & 3, P = cb + Pl;
+  for (int id = tid; id < cn * NCK; id += 256) {  // K image: NCK chunks of 16 B per key, zeros past kd
+    const int Pl = id / NCK, c = id % NCK, P = cb + Pl;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (P < p.N) v = *(const uint4*)(base + (long)P * p.qsw + KD + s4 * 8);
-    *(uint4*)(sK + Pl * 128 + ((s4 ^ (((Pl >> 1) & 3) << 1)) << 4)) = v;
+    if (P < p.N) v = ld8mu(base + (long)P * p.qsw + KD, c * 8, KD);
+    *(uint4*)(sK + Pl * KROW + ((c ^ img_swz<KROW>(Pl)) << 4)) = v;
   }
   __syncthreads();
   for (int ks = 0; ks < cn / 32; ++ks) {
@@ -388,12 +414,16 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
       const int key = cb + 32 * ks + 16 * hi + li;  // this lane's row of the A operands
       const bool kv = key < p.N;
       const T* kp = base + (long)key * p.qsw;
-      const bf16x8_t fk = kv ? ld8(kp + KD + 8 * grp) : zero8();
-      f32x4_t s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < D::KSK; ++k2) {
+        const bf16x8_t fk = kv ? ld8m(kp + KD, 32 * k2 + 8 * grp, KD) : zero8();
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[k2], s, 0, 0, 0);
+      }
       f32x4_t dpt = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const bf16x8_t fv = kv ? ld8(kp + 2 * KD + 32 * k2 + 8 * grp) : zero8();
+      for (int k2 = 0; k2 < D::KSH; ++k2) {
+        const bf16x8_t fv = kv ? ld8m(kp + 2 * KD, 32 * k2 + 8 * grp, HD) : zero8();
         dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fdo[k2], dpt, 0, 0, 0);
       }
 #pragma unroll
@@ -406,13 +436,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) fds[j] = (__bf16)dsv[j];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<128>(sK, ks, dt * 16, grp, qq, pp4), fds, dq[dt], 0, 0, 0);
+    for (int dt = 0; dt < D::NTK; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<KROW>(sK, ks, dt * 16, grp, qq, pp4), fds, dq[dt], 0, 0, 0);
   }
   }
   if (qv) {
     T* dst = (T*)p.dqkv + ((long)b * p.N + q0 + li) * p.gsw + hoff;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
+    for (int dt = 0; dt < D::NTK; ++dt) {
+      if (dt * 16 + 4 * grp >= KD) continue;
       uint2 u;
       u.x = (unsigned)f2bf(dq[dt][0] * p.scale) | ((unsigned)f2bf(dq[dt][1] * p.scale) << 16);
       u.y = (unsigned)f2bf(dq[dt][2] * p.scale) | ((unsigned)f2bf(dq[dt][3] * p.scale) << 16);
@@ -421,10 +452,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnBP p) {
   }
 }
 
+template <int KD, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
   typedef bf16_t T;
-  constexpr int KD = 32, HD = 64;
-  extern __shared__ __attribute__((aligned(16))) char sI[];  // [N32][256 B]: dO (128 B) | Q (64 B) | unused, 32-byte pieces swizzled by row & 7
+  typedef AttnDims<KD, HD> D;
+  constexpr int IROW = D::IROW, HDI = D::HDI;
+  constexpr int NCD = D::NTH * 2, NCQ = D::NTK * 2, NCI = NCD + NCQ;  // chunks per query: dO (zeros past hd) then Q (zeros past kd)
+  extern __shared__ __attribute__((aligned(16))) char sI[];  // [chunk queries][IROW]: dO at column 0, Q at column HDI
   const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp4 = li & 3;
@@ -435,24 +469,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
   const int n32 = (p.N + 31) & ~31;
   const bool kv = k0 + li < p.N;
   const T* kp = base + (long)(k0 + li) * p.qsw;
-  const bf16x8_t fk = kv ? ld8(kp + KD + 8 * grp) : zero8();  // B operands: this lane's key
-  bf16x8_t fv[2];
+  bf16x8_t fk[D::KSK], fv[D::KSH];  // B operands: this lane's key
 #pragma unroll
-  for (int k2 = 0; k2 < 2; ++k2) fv[k2] = kv ? ld8(kp + 2 * KD + 32 * k2 + 8 * grp) : zero8();
+  for (int k2 = 0; k2 < D::KSK; ++k2) fk[k2] = kv ? ld8m(kp + KD, 32 * k2 + 8 * grp, KD) : zero8();
+#pragma unroll
+  for (int k2 = 0; k2 < D::KSH; ++k2) fv[k2] = kv ? ld8m(kp + 2 * KD, 32 * k2 + 8 * grp, HD) : zero8();
   const float* lsep = p.lse + ((long)b * p.nh + h) * p.N;
   const float* delp = p.delta + ((long)b * p.nh + h) * p.N;
-  f32x4_t dv[4], dk[2];
+  f32x4_t dv[D::NTH], dk[D::NTK];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  dk[0] = dk[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < D::NTH; ++i) dv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < D::NTK; ++i) dk[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int cb = 0; cb < n32; cb += p.chunk) {  // the dO | Q image holds p.chunk queries per pass
   const int cn = min(p.chunk, n32 - cb);
   if (cb) __syncthreads();
-  for (int id = tid; id < cn * 12; id += 256) {  // 12 chunks per query: 8 of dO, 4 of Q
-    const int Pl = id / 12, c = id - Pl * 12, P = cb + Pl;
+  for (int id = tid; id < cn * NCI; id += 256) {
+    const int Pl = id / NCI, c = id - Pl * NCI, P = cb + Pl;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (P < p.N) v = c < 8 ? *(const uint4*)(dob + (long)P * p.dsw + c * 8) : *(const uint4*)(base + (long)P * p.qsw + (c - 8) * 8);
-    *(uint4*)(sI + Pl * 256 + ((c ^ ((Pl & 7) << 1)) << 4)) = v;
+    if (P < p.N) v = c < NCD ? ld8mu(dob + (long)P * p.dsw, c * 8, HD) : ld8mu(base + (long)P * p.qsw, (c - NCD) * 8, KD);
+    const int pos = c < NCD ? c : HDI / 8 + (c - NCD);  // chunk position inside the row
+    *(uint4*)(sI + Pl * IROW + ((pos ^ img_swz<IROW>(Pl)) << 4)) = v;
   }
   __syncthreads();
   for (int ks = 0; ks < cn / 32; ++ks) {
@@ -461,12 +498,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
     for (int hi = 0; hi < 2; ++hi) {
       const int qi = cb + 32 * ks + 16 * hi + li;  // this lane's row of the A operands
       const bool qv = qi < p.N;
-      const bf16x8_t fq = qv ? ld8(base + (long)qi * p.qsw + 8 * grp) : zero8();
-      f32x4_t s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fk, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < D::KSK; ++k2) {
+        const bf16x8_t fq = qv ? ld8m(base + (long)qi * p.qsw, 32 * k2 + 8 * grp, KD) : zero8();
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fk[k2], s, 0, 0, 0);
+      }
       f32x4_t dpt = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const bf16x8_t fd = qv ? ld8(dob + (long)qi * p.dsw + 32 * k2 + 8 * grp) : zero8();
+      for (int k2 = 0; k2 < D::KSH; ++k2) {
+        const bf16x8_t fd = qv ? ld8m(dob + (long)qi * p.dsw, 32 * k2 + 8 * grp, HD) : zero8();
         dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fv[k2], dpt, 0, 0, 0);
       }
 #pragma unroll
@@ -482,15 +523,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { fp[j] = (__bf16)pv[j]; fds[j] = (__bf16)dsv[j]; }
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<256>(sI, ks, ct * 16, grp, qq, pp4), fp, dv[ct], 0, 0, 0);
+    for (int ct = 0; ct < D::NTH; ++ct) dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<IROW>(sI, ks, ct * 16, grp, qq, pp4), fp, dv[ct], 0, 0, 0);
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<256>(sI, ks, 64 + dt * 16, grp, qq, pp4), fds, dk[dt], 0, 0, 0);
+    for (int dt = 0; dt < D::NTK; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t<IROW>(sI, ks, HDI + dt * 16, grp, qq, pp4), fds, dk[dt], 0, 0, 0);
   }
   }
   if (kv) {
     T* dst = (T*)p.dqkv + ((long)b * p.N + k0 + li) * p.gsw + hoff;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
+    for (int dt = 0; dt < D::NTK; ++dt) {
+      if (dt * 16 + 4 * grp >= KD) continue;
       uint2 u;
       u.x = (unsigned)f2bf(dk[dt][0] * p.scale) | ((unsigned)f2bf(dk[dt][1] * p.scale) << 16);
       u.y = (unsigned)f2bf(dk[dt][2] * p.scale) | ((unsigned)f2bf(dk[dt][3] * p.scale) << 16);
@@ -498,7 +540,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
     }
     const T* ex = p.dv_extra ? (const T*)p.dv_extra + ((long)b * p.N + k0 + li) * p.esw + h * HD : nullptr;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < D::NTH; ++ct) {
+      if (ct * 16 + 4 * grp >= HD) continue;
       float e[4] = {0.f, 0.f, 0.f, 0.f};
       if (ex) {
 #pragma unroll
@@ -523,13 +566,15 @@ int y3d_attn_fwd(int dtype, const void* qkv, int64_t qsw, void* out, int64_t osw
   AttnP p{qkv, (long)qsw, out, (long)osw, lse, B, N, nh, kd, hd, scale};
   dim3 grid(cdiv(N, 128), B * nh), block(128);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == Y3D_BF16 && kd == 32 && y3d_get_tile_kernels() && qsw % 8 == 0 && osw % 4 == 0) {
+  if (dtype == Y3D_BF16 && y3d_get_tile_kernels() && qsw % 4 == 0 && osw % 4 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KC * 128);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, KC * 128);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<36, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, KC * 256);
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), KC * 128, st, p);
+    if (kd == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 64>), dim3(cdiv(N, 64), B * nh), dim3(256), KC * 128, st, p);
+    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<36, 72>), dim3(cdiv(N, 64), B * nh), dim3(256), KC * 256, st, p);
     Y3D_LAUNCH_CHECK();
     return Y3D_OK;
   }
@@ -553,19 +598,28 @@ int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64
   dim3 grid(cdiv(N, 128), B * nh), block(128);
   hipStream_t st = (hipStream_t)stream;
   const int n32 = (N + 31) & ~31;
-  if (dtype == Y3D_BF16 && kd == 32 && y3d_get_tile_kernels() && qsw % 8 == 0 && osw % 8 == 0 && dsw % 8 == 0 && gsw % 4 == 0 &&
-      (dv_extra == nullptr || esw % 1 == 0)) {
+  if (dtype == Y3D_BF16 && y3d_get_tile_kernels() && qsw % 4 == 0 && osw % 4 == 0 && dsw % 4 == 0 && gsw % 4 == 0 && (dv_extra == nullptr || esw % 1 == 0) &&
+      ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)dout & 7) == 0 && ((uintptr_t)dqkv & 7) == 0) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_q_mfma_kernel<36, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel<36, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    // LDS images of at most 128 KB: 1024 keys (128-byte rows) / 512 queries (256-byte rows) per pass; N = 400 is one pass
+    // LDS images of at most 128 KB: 1024 keys (128-byte rows); 512 queries (256-byte rows) or 256 (512-byte rows) per pass
+    const dim3 g2(cdiv(N, 64), B * nh);
     p.chunk = n32 < 1024 ? n32 : 1024;
-    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)p.chunk * 128, st, p);
-    p.chunk = n32 < 512 ? n32 : 512;
-    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, dim3(cdiv(N, 64), B * nh), dim3(256), (size_t)p.chunk * 256, st, p);
+    if (kd == 32) hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<32, 64>), g2, dim3(256), (size_t)p.chunk * 128, st, p);
+    else hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<36, 72>), g2, dim3(256), (size_t)p.chunk * 128, st, p);
+    if (kd == 32) {
+      p.chunk = n32 < 512 ? n32 : 512;
+      hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<32, 64>), g2, dim3(256), (size_t)p.chunk * 256, st, p);
+    } else {
+      p.chunk = n32 < 256 ? n32 : 256;
+      hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<36, 72>), g2, dim3(256), (size_t)p.chunk * 512, st, p);
+    }
     Y3D_LAUNCH_CHECK();
     return Y3D_OK;
   }
