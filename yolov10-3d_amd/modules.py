@@ -450,16 +450,37 @@ class v10Detect3d(nn.Module):
             elif parts is not None:
                 # cls | 14 regression branches (one grouped conv) | cls over channel views of z1; every split hands ONE gradient back
                 views = ops.SplitChannelsFn.apply(z1, [lo for lo, _, _, _ in parts], [hi - lo for lo, hi, _, _ in parts])
-                feats_s = []
+                fuse = getattr(self, "fuse_bn_proj", True)
+                outs_s, feats_s, k = [None] * 16, [None] * 16, 0
                 for v, (lo, hi, st2, g) in zip(views, parts):
-                    z2 = ops.FusedConvBNActFn.apply(v, st2, g, None, *st2.params())
-                    if g == 1:
-                        feats_s.append(z2)
+                    brs, w = branches[k:k + g], (hi - lo) // g
+                    if fuse and w % 64 == 0:
+                        # this part's grouped conv + BatchNorm statistics + its projections with BatchNorm / SiLU on the fly (the matrix-core
+                        # kernels of proj_bn_mfma.hip at 64 / 128 channels), as on the uniform heads: no activation tensor, no per-branch
+                        # VALU projection launches (M-3D: 32 launches of proj_bwd_weight + 64 slab folds per step)
+                        o = ops.FusedConvBNProjFn.apply(v, st2, g, [j * w for j in range(g)], [w] * g, g, *st2.params(), *[b[2].weight for b in brs],
+                                                        *[b[2].bias for b in brs])
+                        off = 0
+                        for j, b in enumerate(brs):
+                            co = b[2].weight.shape[0]
+                            outs_s[k + j] = o[:, off:off + co]
+                            off += co
                     else:
-                        w = (hi - lo) // g
-                        feats_s.extend(ops.SplitChannelsFn.apply(z2, [j * w for j in range(g)], [w] * g))
-                canon = [branches[pos[c]] for c in range(16)]
-                out = _proj([b[2] for b in canon], [feats_s[pos[c]] for c in range(16)])
+                        z2 = ops.FusedConvBNActFn.apply(v, st2, g, None, *st2.params())
+                        fs = [z2] if g == 1 else ops.SplitChannelsFn.apply(z2, [j * w for j in range(g)], [w] * g)
+                        for j, f in enumerate(fs):
+                            feats_s[k + j] = f
+                    k += g
+                if all(o is not None for o in outs_s):
+                    out = cat([outs_s[pos[c]] for c in range(16)])
+                elif all(f is not None for f in feats_s):
+                    canon = [branches[pos[c]] for c in range(16)]
+                    out = _proj([b[2] for b in canon], [feats_s[pos[c]] for c in range(16)])
+                else:  # mixed: project the un-fused branches one by one, then line the 16 outputs up
+                    for j in range(16):
+                        if outs_s[j] is None:
+                            outs_s[j] = _proj([branches[j][2]], [feats_s[j]])
+                    out = cat([outs_s[pos[c]] for c in range(16)])
             else:
                 feats = [b[1](zj) for b, zj in zip(branches, ops.SplitChannelsFn.apply(z1, offs, mids))]
                 out = _proj([b[2] for b in branches], feats)
