@@ -165,11 +165,13 @@ def main():
     if args.weights == "fp8":
         y3d.set_weight_quant("fp8")
     torch.manual_seed(0)
-    model = y3d.YOLOv10_3DDetectionModel(args.model).to(dev).train()
+    is3d = "3D" in args.model  # the 2D yamls (BASELINE configs[0] / L-2D) run through the same step for profiling
+    model = (y3d.YOLOv10_3DDetectionModel if is3d else y3d.YOLOv10DetectionModel)(args.model).to(dev).train()
     from yolov10_3d_amd.optim import ModelEMA, build_optimizer
     opt = build_optimizer(model)  # reference engine/trainer.py:734-790 groups; fused clip + SGD(nesterov) HIP step
     net = model
-    model.model[-1].restack()  # sibling-branch parameter stacking must be in place before parameters / buffers are recorded
+    if hasattr(model.model[-1], "restack"):
+        model.model[-1].restack()  # sibling-branch parameter stacking must be in place before parameters / buffers are recorded
     ema = ModelEMA(model) if rank == 0 else None  # reference: rank 0 only (engine/trainer.py:294-302), updated in optimizer_step (:574-575)
     reducer = None
     if world > 1 or os.environ.get("Y3D_FORCE_DDP"):
@@ -179,10 +181,11 @@ def main():
             # head-first flat gradient buffer, bucketed RCCL all-reduce on a side stream behind the head backward
             reducer = ddp.FlatGradReducer(model.parameters(), timing=args.phases)
             reducer.broadcast_parameters(model)
-            model.model[-1].restack()  # no-op check: the broadcast wrote in place, the stacked storage is still the parameters' storage
+            if hasattr(model.model[-1], "restack"):
+                model.model[-1].restack()  # no-op check: the broadcast wrote in place, the stacked storage is still the parameters' storage
     B, S = args.batch, args.imgsz
     # NBATCH different batches resident in HBM before the timed region; the loop rotates over them
-    batches = [synth_batch(B, S, S, seed=1 + rank + 1000 * j, device=dev) for j in range(NBATCH)]
+    batches = [synth_batch(B, S, S, seed=1 + rank + 1000 * j, device=dev, nc=model.yaml["nc"]) for j in range(NBATCH)]
     batch = batches[0]
     counter = [0]
     phase_ev = []

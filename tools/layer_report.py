@@ -14,10 +14,11 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 dev = torch.device("cuda", 0)
 y3d.set_compute_dtype(torch.bfloat16)
 torch.manual_seed(0)
-model = y3d.YOLOv10_3DDetectionModel(name).to(dev).train()
+model = (y3d.YOLOv10_3DDetectionModel if "3D" in name else y3d.YOLOv10DetectionModel)(name).to(dev).train()
 opt = build_optimizer(model)
-model.model[-1].restack()
-batch = synth_batch(B, S, S, 1, dev)
+if hasattr(model.model[-1], "restack"):
+    model.model[-1].restack()
+batch = synth_batch(B, S, S, 1, dev, nc=model.yaml["nc"])
 
 
 def step():
