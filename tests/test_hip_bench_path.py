@@ -755,3 +755,73 @@ def test_conv3x3s2_dgrad_resident_tile_matches_generic_and_exact(shape):
     assert ref.shape == outs[0].shape
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], ref)
+
+
+def test_random_conv_geometries_new_kernels_vs_generic():
+    """Seeded sweep over conv geometries (1x1 / 3x3, strides 1 / 2, channel counts around the kernels' tile widths, ragged maps, batch 1..5):
+    the round-2 kernels (streaming 1x1, narrow 3x3, stride-2 data gradient, their weight gradients) against the generic implicit GEMM
+    on small-integer operands, where every path must give the SAME exact integers for y, dx and dW."""
+    import random
+    rnd = random.Random(7)
+    L = y3d.lib()
+    y3d.set_compute_dtype(torch.bfloat16)
+    chans = [8, 16, 24, 32, 40, 48, 64, 72, 96, 128, 136, 160, 192, 256, 264, 320, 384, 512]
+    done = 0
+    while done < 36:
+        k = rnd.choice([1, 1, 3, 3])
+        s = 1 if k == 1 else rnd.choice([1, 1, 2])
+        cin, cout = rnd.choice(chans), rnd.choice(chans)
+        if k == 3 and s == 1 and (cin > 64 or cout > 64):
+            continue  # the wide 3x3 kernels have their own tests above
+        B, H, W = rnd.randint(1, 5), rnd.randint(6, 41), rnd.randint(8, 45)
+        if cin * cout * k * k * H * W * B > 3e9:
+            continue
+        done += 1
+        p = k // 2
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        g = torch.Generator().manual_seed(done)
+        xf, wf, dyf = _sparse_int((B, cin, H, W), g, 0.25), _sparse_int((cout, cin, k, k), g, 0.25), _sparse_int((B, cout, Ho, Wo), g, 0.25)
+        ref_y = F.conv2d(xf, wf, stride=s, padding=p)
+        if float(ref_y.abs().max()) > 256:
+            continue
+        outs = []
+        for flag in (1, 0):
+            old = L.set_stream1x1(flag)
+            try:
+                st, dt, bf = ops.stream(), BF16, torch.bfloat16
+                xin = ops.nhwc_empty(B, cin, H, W, bf, DEV)
+                xin.copy_(xf.to(DEV))
+                dyd = ops.nhwc_empty(B, cout, Ho, Wo, bf, DEV)
+                dyd.copy_(dyf.to(DEV))
+                wd = wf.to(DEV).contiguous()
+                sb, sh, sw = ops.s3(xin)
+                wp = torch.empty(cout * k * k * cin, dtype=bf, device=DEV)
+                L.pack_weight_fwd(dt, wd.data_ptr(), wp.data_ptr(), cout, cin, cin, k, k, st)
+                nblk = L.conv2d_stat_rows(dt, B, H, W, cin, cout, 1, k, k, s, p)
+                part = torch.full((nblk, cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+                y = ops.nhwc_empty(B, cout, Ho, Wo, bf, DEV)
+                L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, cin, wp.data_ptr(), None, y.data_ptr(), cout, Ho, Wo, cout, 1, k, k, s, p, part.data_ptr(), st)
+                kp = L.conv_kpad(dt, k * k * cout)
+                wpd = torch.empty(cin * kp, dtype=bf, device=DEV)
+                L.pack_weight_dgrad(dt, wd.data_ptr(), wpd.data_ptr(), cout, cin, 1, k, k, st)
+                dx = ops.nhwc_empty(B, cin, H, W, bf, DEV)
+                dsb, dsh, dsw = ops.s3(dyd)
+                L.conv2d_bwd_data(dt, dyd.data_ptr(), dsb, dsh, dsw, B, Ho, Wo, cout, wpd.data_ptr(), dx.data_ptr(), cin, H, W, cin, 1, k, k, s, p, st)
+                ns = L.conv2d_wgrad_plan(dt, B, H, W, cin, cout, 1, k, k, s, p)
+                slab = torch.full((ns * cout * k * k * cin,), float("nan"), dtype=torch.float32, device=DEV)
+                dW = torch.empty_like(wd)
+                L.conv2d_bwd_weight(dt, xin.data_ptr(), sb, sh, sw, B, H, W, cin, cin, dyd.data_ptr(), cout, Ho, Wo, cout, 1, k, k, s, p, slab.data_ptr(), ns,
+                                    dW.data_ptr(), 0, st)
+                torch.cuda.synchronize()
+                outs.append((y.float().cpu(), part.double().sum(0).cpu(), dx.float().cpu(), dW.cpu()))
+            finally:
+                L.set_stream1x1(old)
+        tag = f"k{k} s{s} {cin}->{cout} B{B} {H}x{W}"
+        ref_dx = torch.nn.grad.conv2d_input(xf.shape, wf, dyf, stride=s, padding=p)
+        ref_dw = torch.nn.grad.conv2d_weight(xf, wf.shape, dyf, stride=s, padding=p)
+        ref_st = torch.stack((ref_y.double().sum((0, 2, 3)), (ref_y.double() ** 2).sum((0, 2, 3))), 1)
+        for (yy, stt, dxx, dww), which in zip(outs, ("new kernels", "generic")):
+            assert torch.equal(yy, ref_y), f"{tag}: y ({which})"
+            assert torch.equal(stt, ref_st), f"{tag}: BatchNorm partial sums ({which})"
+            assert torch.equal(dxx, ref_dx), f"{tag}: dx ({which})"
+            assert torch.equal(dww, ref_dw), f"{tag}: dW ({which})"
