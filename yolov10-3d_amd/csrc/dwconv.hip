@@ -55,7 +55,36 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
 #pragma unroll
       for (int j = 0; j < CE; ++j) acc[j] = 0.f;
       const T* xb = X + (long)b * p.xsb + c;
-      if (K > 0) {
+      if (K == 3 && DGRAD && p.stride == 2) {
+        // stride-2 data gradient: only the taps whose parity matches the pixel reach dy - rows r0, r0 + 2 with r0 = (hq + pad) & 1
+        // (one or two of three), columns likewise: at most 4 tap slots instead of 9, no division (the generic form below spent its
+        // time on 18 integer divisions and 9 mostly masked taps per pixel: 1.2 TB/s against 4.1 for the forward)
+        const int r0 = (hq + p.pad) & 1, q0 = (wq + p.pad) & 1;
+        uint4 raw[2][2];
+        int tapi[2][2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int r = r0 + 2 * rr, th = hq + p.pad - r, hh = th >> 1;
+          const bool okh = r < 3 && th >= 0 && hh < p.Hg;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const int q = q0 + 2 * qq, tw = wq + p.pad - q, ww = tw >> 1;
+            const bool ok = okh && q < 3 && tw >= 0 && ww < p.Wg;
+            raw[rr][qq] = ok ? *(const uint4*)(xb + (long)hh * p.xsh + (long)ww * p.xsw) : make_uint4(0, 0, 0, 0);
+            tapi[rr][qq] = ok ? r * 3 + q : 0;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            float v[CE];
+            Chunk<T>::unpack(raw[rr][qq], v);
+            const float* wt = sw + tapi[rr][qq] * 64 + ct * CE;
+#pragma unroll
+            for (int j = 0; j < CE; ++j) acc[j] += v[j] * wt[j];
+          }
+      } else if (K > 0) {
         // K = 7: one filter row (7 loads) in flight at a time -- unrolled over all 49 taps the kernel needed 512 VGPRs and spilled
 #pragma unroll K == 3 ? 3 : 1
         for (int r = 0; r < K; ++r) {
