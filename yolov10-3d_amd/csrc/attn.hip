@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
   typedef bf16_t T;
   typedef AttnDims<KD, HD> D;
   constexpr int IROW = D::IROW, HDI = D::HDI;
-  constexpr int NCD = D::NTH * 2, NCQ = D::NTK * 2, NCI = NCD + NCQ;  // chunks per query: dO (zeros past hd) then Q (zeros past kd)
+  constexpr int NCD = D::KSH * 4, NCQ = D::KSK * 4, NCI = NCD + NCQ;  // chunks per query: dO then Q, whole 32-element K steps (zeros past hd / kd)
   extern __shared__ __attribute__((aligned(16))) char sI[];  // [chunk queries][IROW]: dO at column 0, Q at column HDI
   const int bh = blockIdx.y, b = bh / p.nh, h = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,32 +491,42 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnBP p) {
     const int pos = c < NCD ? c : HDI / 8 + (c - NCD);  // chunk position inside the row
     *(uint4*)(sI + Pl * IROW + ((pos ^ img_swz<IROW>(Pl)) << 4)) = v;
   }
+  // log-sum-exp and delta of the pass's queries next to the image: the inner loop reads nothing from global memory (its Q / dO
+  // fragments come out of the image as plain 16-byte rows; with per-step global loads the loop ran at their latency: 172 us at N = 400)
+  float* sLse = (float*)(sI + (size_t)p.chunk * IROW);
+  float* sDel = sLse + p.chunk;
+  for (int id = tid; id < cn; id += 256) {
+    const int P = cb + id;
+    sLse[id] = P < p.N ? lsep[P] : 0.f;
+    sDel[id] = P < p.N ? delp[P] : 0.f;
+  }
   __syncthreads();
   for (int ks = 0; ks < cn / 32; ++ks) {
     float pv[8], dsv[8];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
-      const int qi = cb + 32 * ks + 16 * hi + li;  // this lane's row of the A operands
-      const bool qv = qi < p.N;
+      const int ql = 32 * ks + 16 * hi + li;  // this lane's row of the A operands (image row; rows past N are zeros)
+      const char* row = sI + ql * IROW;
+      const int sz = img_swz<IROW>(ql);
       f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k2 = 0; k2 < D::KSK; ++k2) {
-        const bf16x8_t fq = qv ? ld8m(base + (long)qi * p.qsw, 32 * k2 + 8 * grp, KD) : zero8();
+        const bf16x8_t fq = __builtin_bit_cast(bf16x8_t, *(const uint4*)(row + (((HDI / 8 + 4 * k2 + grp) ^ sz) << 4)));
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fk[k2], s, 0, 0, 0);
       }
       f32x4_t dpt = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k2 = 0; k2 < D::KSH; ++k2) {
-        const bf16x8_t fd = qv ? ld8m(dob + (long)qi * p.dsw, 32 * k2 + 8 * grp, HD) : zero8();
+        const bf16x8_t fd = __builtin_bit_cast(bf16x8_t, *(const uint4*)(row + (((4 * k2 + grp) ^ sz) << 4)));
         dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fv[k2], dpt, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qr = cb + 32 * ks + 16 * hi + 4 * grp + r;  // the query of register r
-        const bool ok = kv && qr < p.N;
-        const float pe = ok ? __expf(s[r] * p.scale - lsep[qr]) : 0.f;
+        const int qrl = 32 * ks + 16 * hi + 4 * grp + r;  // the query of register r (row of this pass)
+        const bool ok = kv && cb + qrl < p.N;
+        const float pe = ok ? __expf(s[r] * p.scale - sLse[qrl]) : 0.f;
         pv[hi * 4 + r] = pe;
-        dsv[hi * 4 + r] = ok ? pe * (dpt[r] - delp[qr]) : 0.f;
+        dsv[hi * 4 + r] = ok ? pe * (dpt[r] - sDel[qrl]) : 0.f;
       }
     }
     bf16x8_t fp, fds;
@@ -615,10 +625,10 @@ int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64
     else hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<36, 72>), g2, dim3(256), (size_t)p.chunk * 128, st, p);
     if (kd == 32) {
       p.chunk = n32 < 512 ? n32 : 512;
-      hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<32, 64>), g2, dim3(256), (size_t)p.chunk * 256, st, p);
+      hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<32, 64>), g2, dim3(256), (size_t)p.chunk * (256 + 8), st, p);
     } else {
       p.chunk = n32 < 256 ? n32 : 256;
-      hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<36, 72>), g2, dim3(256), (size_t)p.chunk * 512, st, p);
+      hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<36, 72>), g2, dim3(256), (size_t)p.chunk * (512 + 8), st, p);
     }
     Y3D_LAUNCH_CHECK();
     return Y3D_OK;
