@@ -544,11 +544,11 @@ def _conv1x1_abi(x, w, dy, bias=None, affine=None, stream=True):
     wd = w.to(DEV).contiguous()
     wp = torch.empty(Cout * Cin, dtype=bf, device=DEV)
     L.pack_weight_fwd(dt, wd.data_ptr(), wp.data_ptr(), Cout, Cin, Cin, 1, 1, st)
-    nblk = L.conv2d_stat_rows(dt, B, H, W, Cin, Cout, 1, 1, 1, 1, 0)
-    part = torch.full((nblk, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
     y = ops.nhwc_empty(B, Cout, H, W, bf, DEV)
     old = L.set_stream1x1(1 if stream else 0)
     try:
+        nblk = L.conv2d_stat_rows(dt, B, H, W, Cin, Cout, 1, 1, 1, 1, 0)  # depends on the kernel the entry point will pick
+        part = torch.full((nblk, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
         if affine is not None:
             sc, sf = (t.to(DEV).contiguous() for t in affine)
             L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), sc.data_ptr(), sf.data_ptr(), 1, y.data_ptr(), Cout, H, W,

@@ -32,7 +32,9 @@ def run(L, st, dt, B, H, Cin, Cout, reps, stream_on):
     sb, sh, sw = ops.s3(x)
     wp = torch.empty(Cout * Cin, dtype=bf, device=DEV)
     L.pack_weight_fwd(dt, w.data_ptr(), wp.data_ptr(), Cout, Cin, Cin, 1, 1, st)
-    nblk = L.conv2d_stat_rows(dt, B, H, H, Cin, Cout, 1, 1, 1, 1, 0)
+    old0 = L.set_stream1x1(1 if stream_on else 0)
+    nblk = L.conv2d_stat_rows(dt, B, H, H, Cin, Cout, 1, 1, 1, 1, 0)  # depends on the kernel the entry point will pick
+    L.set_stream1x1(old0)
     part = torch.zeros((nblk, Cout, 2), dtype=torch.float32, device=DEV)
     y = ops.nhwc_empty(B, Cout, H, H, bf, DEV)
     kp = L.conv_kpad(dt, Cout)

@@ -9,7 +9,7 @@
 // 8 x 16 pixel tiles, the (8 + 2) x (16 + 2) halo of a tile arrives by LDS-DMA (double buffered: the next tile in flight under the
 // MFMAs and the stores of this one; the counted s_waitcnt leaves exactly the stores of a wave outstanding), all nine taps read
 // their shifted windows out of it.  BatchNorm partial sums stay per lane over all tiles of a workgroup and are folded once
-// (row = workgroup index, the remaining rows of the caller's partial buffer are zero-filled).
+// (row = workgroup index: y3d_conv2d_stat_rows returns the workgroup count for the shapes this kernel takes).
 #include "common.h"
 
 namespace {
@@ -182,9 +182,6 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
       dst[0] = s;
       dst[1] = q;
     }
-    // rows nobody owns: zeros (the finalize pass sums every row of the caller's buffer)
-    for (int row = wk + nwk; row < p.rows; row += nwk)
-      for (int c = tid; c < p.Cout; c += 256) *(float2*)(p.part + ((long)row * p.Cout + c) * 2) = make_float2(0.f, 0.f);
   }
 }
 
@@ -210,6 +207,15 @@ int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int 
   return 1;
 }
 
+// workgroups (= rows of BatchNorm partials) for this shape
+int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout) {
+  const int nct = cdiv(Cout, 16), cb = Cin * 2;
+  const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
+  const long ntiles = (long)B * cdiv(H, 8) * cdiv(W, 16);
+  const long grid = 256 * (lds <= 80 * 1024 ? 2 : 1);
+  return (int)(grid < ntiles ? grid : ntiles);
+}
+
 int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
                              long ysw, float* part, int rows, int flip, void* stream) {
   Y3D_CHECK(((uintptr_t)x & 15) == 0 && xsb % 8 == 0 && xsh % 8 == 0 && xsw % 8 == 0 && ((uintptr_t)w & 15) == 0 && Ktot % 8 == 0 &&
@@ -227,9 +233,9 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
   const int nct = cdiv(Cout, 16);
   const int cb = Cin * 2;
   const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
-  int grid = 256 * (lds <= 80 * 1024 ? 2 : 1);
-  if (grid > p.ntiles) grid = p.ntiles;
-  if (part && grid > rows) grid = rows;
+  (void)lds;
+  const int grid = y3d_conv3x3_small_rows(B, H, W, Cin, Cout);
+  Y3D_CHECK(!part || rows == grid, "conv3x3_small: the partial buffer must have y3d_conv2d_stat_rows rows (%d given, %d written)", rows, grid);
   hipStream_t st = (hipStream_t)stream;
 #define SM_GO(CB)                                                   \
   switch (nct) {                                                    \

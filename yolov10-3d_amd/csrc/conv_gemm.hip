@@ -773,6 +773,8 @@ int y3d_conv3x3s2_dgrad_launch(const void* dy, long dsw, int B, int Ho, int Wo, 
 int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int rows);
 int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
                              long ysw, float* part, int rows, int flip, void* stream);
+int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout);
+int y3d_conv1x1_stream_rows(long M, int K, int N);
 extern "C" int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
 // wgrad3x3_small.hip
 int y3d_wgrad3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout);
@@ -818,6 +820,11 @@ int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int
 }
 
 int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
+  // the persistent kernels write one row per workgroup (a few hundred rows whatever the map size)
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && y3d_conv1x1_stream_ok(dtype, (long)B * H * W, Cin, Cout, Cin))
+    return y3d_conv1x1_stream_rows((long)B * H * W, Cin, Cout);
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, 1))
+    return y3d_conv3x3_small_rows(B, H, W, Cin, Cout);
   int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, B, H, W, Cin / groups, Cout / groups, groups, kh, kw, stride, pad) : 0;
   if (th) return B * cdiv(H, th) * cdiv(W, 16);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
@@ -888,6 +895,10 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
   if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, H, W, xsb, xsh, xsw) &&
       y3d_conv1x1_stream_ok(dtype, p.M, Cin, Cout, xsw))
     return y3d_conv1x1_stream_launch(x, xsw, w_packed, p.Kpad, bias, scale, shift, act, y, ysw, stat_partials, p.M, Cin, Cout, stream);
+  // y3d_conv2d_stat_rows sized the caller's partial buffer for the streaming kernel: an operand it cannot take (a view that is not
+  // pixel-dense, or beyond 32-bit byte offsets) must not fall through to the generic kernel's one-row-per-tile layout
+  Y3D_CHECK(!(stat_partials && kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && y3d_conv1x1_stream_ok(dtype, p.M, Cin, Cout, Cin)),
+            "conv2d_fwd: 1x1 input view must be pixel-dense and below 4 GB for the BatchNorm partial layout of this shape");
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && !bias && !scale) {
     const int rows = stat_partials ? y3d_conv2d_stat_rows(dtype, B, H, W, Cin, Cout, groups, kh, kw, stride, pad) : 1;
     if (y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, rows))
