@@ -374,8 +374,10 @@ int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, co
 }
 
 int y3d_bn_bwd_blocks(int64_t P, int C) {
-  // pixel runs of >= 512 pixels; (runs) x (64-channel slabs) ~ 8 workgroups per CU, at most 2048 rows for the finalize pass
-  long n = (P + 511) / 512;
+  // pixel runs of >= 128 pixels; (runs) x (64-channel slabs) ~ 8 workgroups per CU, at most 2048 rows for the finalize pass.  (Runs of
+  // >= 512 pixels left the 20x20 / 40x40 tensors with 200 workgroups of 16 dependent pixel steps each: 15-17 us for 13 MB, twice the
+  // apply pass that writes as well.)
+  long n = (P + 127) / 128;
   long cap = 2048 / cdiv(C, 64);
   if (cap < 64) cap = 64;
   if (n > cap) n = cap;
