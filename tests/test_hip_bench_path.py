@@ -275,7 +275,9 @@ def test_stacked_head_under_torch_optim_matches_fused_sgd():
     for step in range(3):
         la, ia = ma(batch)
         lb, ib = mb(batch)
-        assert torch.allclose(ia, ib, rtol=2e-4, atol=1e-5), f"step {step}: loss items diverged: {ia} vs {ib}"
+        # stale packed weights would move the items by O(1); the two optimizers' different rounding alone, amplified by the discrete
+        # assignment over three steps, has been seen at 3e-4 relative
+        assert torch.allclose(ia, ib, rtol=1e-3, atol=1e-5), f"step {step}: loss items diverged: {ia} vs {ib}"
         la.backward()
         lb.backward()
         oa.step()
