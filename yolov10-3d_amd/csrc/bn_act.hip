@@ -198,12 +198,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
   int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
   int c = blockIdx.x * 8 + cx;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int b = ry; b < nblk; b += 32) {
-      float2 v = *(const float2*)(part + ((long)b * C + c) * 2);
+  if (c < C) {
+    // four rows in flight per thread, fixed summation order (as bn_finalize_kernel): up to 2048 partial rows
+    int b = ry;
+    for (; b + 96 < nblk; b += 128) {
+      const float2 v0 = *(const float2*)(part + ((long)b * C + c) * 2), v1 = *(const float2*)(part + ((long)(b + 32) * C + c) * 2);
+      const float2 v2 = *(const float2*)(part + ((long)(b + 64) * C + c) * 2), v3 = *(const float2*)(part + ((long)(b + 96) * C + c) * 2);
+      s += (double)v0.x; q += (double)v0.y;
+      s += (double)v1.x; q += (double)v1.y;
+      s += (double)v2.x; q += (double)v2.y;
+      s += (double)v3.x; q += (double)v3.y;
+    }
+    for (; b < nblk; b += 32) {
+      const float2 v = *(const float2*)(part + ((long)b * C + c) * 2);
       s += (double)v.x;
       q += (double)v.y;
     }
+  }
   sh[ry][cx][0] = s;
   sh[ry][cx][1] = q;
   __syncthreads();
