@@ -590,6 +590,7 @@ STREAM_SHAPES = [
     (16, 40, 40, 256, 0, 256, 256),    # two resident tiles would stream the pixels twice: one streamed 256-channel tile
     (2, 24, 24, 48, 0, 48, 96),        # K = 48 (M-model widths): the second MFMA step of the only K chunk is half zeros
     (2, 20, 20, 336, 8, 144, 288),     # K = 144 = 2 chunks + 16, a slice view at channel offset 8, streamed weights (N > 256)
+    (16, 64, 64, 256, 0, 256, 264),    # a large streamed-weight GEMM: 512 pixel tiles x two channel tiles
 ]
 
 
