@@ -62,10 +62,31 @@ def synth_batch(B, H, W, seed, device, nc=3):
     return {k: v.to(device) for k, v in batch.items()}
 
 
+def conv_key_flops(key):
+    """algorithmic FLOPs of one launch of an ops._timed conv key: 2 * B * Ho * Wo * Cout * (Cin / g) * k * k"""
+    _, _, B, H, W, Cin, Cout, k, s, g = key
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    return 2.0 * B * Ho * Wo * Cout * (Cin // g) * k * k
+
+
+def roofline_key(model, seen, dt_code, B, S):
+    """the launch bench.py's `roofline` object describes.  3D heads: the fused second head layer at the stride-8 level (16 sibling
+    128->128 3x3 convs as ONE grouped launch, SURVEY §0.4's 54 %-of-FLOPs shape).  2D models (no stacked head): the 3x3 stride-1
+    forward launch with the most algorithmic FLOPs among the launches a warm-up step made."""
+    head = model.model[-1]
+    if hasattr(head, "o2o_heads"):
+        mid = head.o2o_heads[0][0][1].conv.in_channels
+        k2 = head.o2o_heads[0][0][1].conv.kernel_size[0]
+        if k2 == 3 and len({h[0][1].conv.in_channels for h in head.o2o_heads}) == 1:
+            return ("conv_fwd", dt_code, B, S // 8, S // 8, 16 * mid, 16 * mid, 3, 1, 16)
+    cands = [k for k in seen if k[0] == "conv_fwd" and k[7] == 3 and k[8] == 1]
+    return max(cands, key=lambda k: (conv_key_flops(k), k)) if cands else None
+
+
 NBATCH = 4
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (torch.distributed.run), before this
     process has made any HIP call, hand through stdout / stderr (rank 0 prints the JSON line) and return the child's exit code."""
     import socket
@@ -78,7 +99,7 @@ def spawn_ranks(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's buffer exchange needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
     return subprocess.call(cmd, env=env)
 
 
@@ -122,7 +143,7 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -137,17 +158,21 @@ def main():
     ap.add_argument("--infer-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--phases", action="store_true", help="N>1: per-phase device times (backward / all-reduce / optimizer) in the JSON line")
-    args = ap.parse_args()
+    ap.add_argument("--phases", action="store_true", help="per-phase device times (backward / all-reduce / optimizer) in the JSON line (default for N > 1)")
+    ap.add_argument("--no-phases", action="store_true", help="N > 1: no per-phase events")
+    ap.add_argument("--graph", action="store_true", help="replay the eval forward + postprocess from a captured hipGraph (inference leg)")
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and not args.no_phases:
+        args.phases = True  # four event records per step; the exposed all-reduce time is what a scaling run is read for
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))  # nothing in this process has touched the GPU yet
+        sys.exit(spawn_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv)))  # nothing in this process has touched the GPU yet
 
     import torch.distributed as dist
 
     import yolov10_3d_amd as y3d
     from yolov10_3d_amd import ops
-    from yolov10_3d_amd.loss import v10_3Dpostprocess
+    from yolov10_3d_amd.loss import v10_3Dpostprocess, v10postprocess
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -211,7 +236,7 @@ def main():
         opt.step(max_norm=10.0)  # clip_grad_norm_(10) + SGD nesterov (trainer.py:570-571) in three multi-tensor launches
         opt.zero_grad(set_to_none=True)
         if ema is not None:
-            ema.update(model)  # one multi-tensor launch over the whole state_dict
+            ema.update(model, guard=opt.last_norm)  # one multi-tensor launch over the whole state_dict; skipped with a skipped step
         if ev:
             ev[3].record()
             phase_ev.append(ev)
@@ -224,17 +249,22 @@ def main():
             torch.cuda.synchronize()
 
     log(f"model {args.model} built, {sum(p.numel() for p in model.parameters()) / 1e6:.2f} M params; warm-up {args.warmup} steps")
+    seen = {}
+
+    def collect(key):  # a warm-up pass records every conv launch key (nothing is bracketed): the 2D models pick their roofline launch from it
+        seen[key] = seen.get(key, 0) + 1
+        return False
+
     for i in range(args.warmup):
         tw = time.perf_counter()
+        if i == args.warmup - 1:
+            ops.TIMER = ops.KernelTimer(collect)
         items = step()
+        ops.TIMER = None
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - tw):.1f} ms, loss items {[round(float(v), 3) for v in items.float().cpu()]}")
-    # headline kernel: the 3x3 s1 128->128 conv forward on the 80x80 (stride-8) map — SURVEY §0.4's 54 %-of-FLOPs shape.  The
-    # 16 sibling instances (8 branches x 2 head sets, second conv of each) run as ONE grouped launch: 16 groups of 128->128.
-    P3 = S // 8
     dt_code = 1 if dtype == torch.bfloat16 else 0
-    mid = model.model[-1].o2o_heads[0][0][1].conv.in_channels
-    k1_key = ("conv_fwd", dt_code, B, P3, P3, 16 * mid, 16 * mid, 3, 1, 16)
+    k1_key = roofline_key(model, seen, dt_code, B, S)
     ops.TIMER = ops.KernelTimer(lambda key: key == k1_key)
     phase_ev.clear()
     sync()
@@ -255,15 +285,21 @@ def main():
     # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190)
     model.eval()
     infer_ips = None
+    nc = model.yaml["nc"]
+
+    def infer_once():
+        y = model(batch["img"])["one2one"][0]
+        if is3d:
+            return v10_3Dpostprocess(y.permute(0, 2, 1), 50, nc)
+        return v10postprocess(y.permute(0, 2, 1), 300, nc)
+
     with torch.no_grad():
         for _ in range(2 if args.infer_steps > 0 else 0):
-            y = model(batch["img"])["one2one"][0]
-            v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
+            infer_once()
         sync()
         t1 = time.perf_counter()
         for _ in range(args.infer_steps):
-            y = model(batch["img"])["one2one"][0]
-            v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
+            infer_once()
         sync()
         ti = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         if world > 1:
@@ -272,23 +308,27 @@ def main():
     log(f"infer: {infer_ips:.1f} images/s" if infer_ips else "infer: skipped")
 
     if rank == 0:
-        res = timer.results().get(k1_key, [])
+        res = timer.results().get(k1_key, []) if k1_key is not None else []
         roof = None
         if res:
             avg_ms = sum(res) / len(res)
-            flops = 2.0 * B * P3 * P3 * 16 * mid * mid * 9
+            _, _, kB, kH, kW, kCin, kCout, kk, ks, kg = k1_key
+            flops = conv_key_flops(k1_key)
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
             # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the run, so this is the figure of the
             # committed rocprofv3 passes over this same command (tools/pmc_summary.py), labelled with the commit they were taken at
             traffic, traffic_src = None, None
             pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_headline.json")
-            if os.path.exists(pj) and dtype == torch.bfloat16 and B == 32 and S == 640:
+            default_cfg = args.model == "yolov10s_3D.yaml" and dtype == torch.bfloat16 and B == 32 and S == 640 and args.weights == "full"
+            if os.path.exists(pj) and default_cfg:
                 with open(pj) as f:
                     pm = json.load(f)
                 traffic = pm.get("traffic_bytes_per_launch")
                 traffic_src = "profiles/pmc_headline.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s)" % pm.get("commit", "?")
-            roof = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<TH=16> %s (persistent resident-halo implicit GEMM) 3x3 s1, 16 groups of %d->%d @%dx%d B=%d (fused head layer 2)" % (args.dtype, mid, mid, P3, P3, B),
+            what = "fused head layer 2" if kg == 16 else "largest 3x3 s1 forward launch of the step"
+            roof = {"bound": "mfma", "kernel": "3x3 s1 conv forward %s (persistent resident-halo implicit GEMM, csrc/conv3x3_wide.hip), %s @%dx%d B=%d (%s)"
+                    % (args.dtype, ("%d groups of %d->%d" % (kg, kCin // kg, kCout // kg)) if kg > 1 else "%d->%d" % (kCin, kCout), kH, kW, kB, what),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None
@@ -300,8 +340,10 @@ def main():
             "metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype if args.weights == "full" else "fp8w", "data": "synthetic",
-            "config": {"workload": f"{args.model} (3D head), {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' on fp8 e4m3 conv weights'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
+            "config": {"workload": f"{args.model}{' (3D head)' if is3d else ' (2D head)'}, {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' on fp8 e4m3 conv weights'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": args.backend if dist.is_initialized() else None,
+            "steps_skipped_nonfinite": int(opt.last_norm[4]) if opt.last_norm is not None else None,
             "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None,
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],
             "roofline": roof, "cpu_baseline": cpu,

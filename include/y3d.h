@@ -236,8 +236,10 @@ int y3d_attn_bwd(int dtype, const void* qkv, int64_t qsw, const void* out, int64
 int y3d_tal3d_scratch_floats(int B, int n, int A, int topk);
 /* `preprocess` utils/loss.py:795-810 (3D: :848-856, 2D: :223-226): rows (nbox, 1+width) = [batch_idx | cls | box xywh in [0,1] | ...] ->
  * out (B, cap, width) zero-padded per image in order of appearance, box scaled by (scale_x, scale_y) and converted to xyxy px.
- * *n_used (device int) = largest per-image box count: the assigners take it as a DEVICE pointer, so — unlike the reference's
- * host-side `counts.max()` — padding the targets needs no host synchronisation.  Boxes beyond `cap` per image are dropped. */
+ * n_used: TWO device ints.  n_used[0] = min(largest per-image box count, cap): the assigners take it as a DEVICE pointer, so —
+ * unlike the reference's host-side `counts.max()` — padding the targets needs no host synchronisation.  n_used[1] = the largest
+ * count itself: boxes beyond `cap` per image are dropped, and a caller must treat n_used[1] > cap as an error (loss.pad_targets
+ * reads it back asynchronously and raises). */
 int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, float scale_x, float scale_y, float* out, int* n_used,
                     void* stream);
 /* outputs: fg_mask (B,A) uint8, target_gt_idx (B,A) int32, target_scores (B,A,nc) fp32 (normalised),
@@ -341,9 +343,10 @@ int y3d_mt_adamw(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int6
                  float eps, float bias_corr1, float bias_corr2_sqrt, const float* norm_clip, void* stream);
 /* ModelEMA.update (utils/torch_utils.py:431-443, called from optimizer_step engine/trainer.py:574-575): e = e*decay + (1-decay)*m over
  * every floating-point state_dict tensor, reps[t] times for tensor t (the reference walks state_dict KEYS, and the aliased one-to-one
- * head branches appear under two keys each) */
+ * head branches appear under two keys each).  guard: NULL, or y3d_mt_clip_coef's array — the update is then a no-op when
+ * guard[2] == 0 (it follows an optimizer step that was skipped) */
 int y3d_mt_ema(const int64_t* ema_ptrs, const int64_t* model_ptrs, const int64_t* sizes, const int* reps, const int* chunk_tensor,
-               const int* chunk_off, int nchunks, int chunk, float decay, float one_minus_decay, void* stream);
+               const int* chunk_off, int nchunks, int chunk, float decay, float one_minus_decay, const float* guard, void* stream);
 
 #ifdef __cplusplus
 }

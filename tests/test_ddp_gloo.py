@@ -267,3 +267,82 @@ def test_shard_batch_partitions_boxes():
         n += loc["batch_idx"].numel()
         assert loc["img"].shape[0] == 2 and loc["depth"].shape == loc["batch_idx"].shape
     assert n == full["batch_idx"].numel()
+
+
+def _worker_accum(rank, world, port, ret):
+    """two micro-steps per optimizer step (no_sync + final), a parameter that has a gradient in step 0 only (stale
+    slot), and the misuse the contract forbids (backward into an already reduced slot) raising instead of double-reducing"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddp.init("gloo")
+    torch.manual_seed(0)
+    net = TinyNet()
+    extra = torch.nn.Parameter(torch.ones(5))  # gets a gradient in step 0 on every rank, in step 1 on rank 1 only
+    params = list(net.parameters()) + [extra]
+    red = _CpuReducer(params, bucket_mb=0.0005, overlap=True)
+    red.broadcast_parameters(net)
+    micro = [ddp.shard_batch(_make_batch(seed=s), rank, world) for s in (0, 1)]
+    out = {}
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        with red.no_sync():
+            loss, _ = net(micro[0])
+            if step == 0 or rank == 1:
+                loss = loss + (extra * (1.0 + rank + step)).sum()
+            loss.backward()
+            with pytest.raises(RuntimeError):
+                red.finish()
+        loss, _ = net(micro[1])
+        loss.backward()
+        red.finish()
+        out[step] = [None if p.grad is None else p.grad.clone() for p in params]
+    # misuse: a second backward without clearing the gradients accumulates into the reduced slots
+    loss, _ = net(micro[0])
+    with pytest.raises(RuntimeError, match="already all-reduced"):
+        loss.backward()
+        red.finish()
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_reducer_accumulation_and_stale_slots():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_accum, args=(world, port, ret), nprocs=world, join=True)
+    torch.manual_seed(0)
+    net = TinyNet()
+    for s in (0, 1):  # single process: both micro-batches, whole
+        loss, _ = net(_make_batch(seed=s))
+        loss.backward()
+    ref = [p.grad for p in net.parameters()]
+    for r in range(world):
+        for step in range(2):
+            got = ret[r][step]
+            for a, b in zip(got[:-1], ref):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (step, (a - b).abs().max())
+        # step 0: every rank contributes 1 + rank; step 1: only rank 1 (2 + 1): rank 0's stale step-0 slot must not be added again
+        assert torch.allclose(ret[r][0][-1], torch.full((5,), 1.0 + 2.0))
+    assert ret[0][1][-1] is None  # rank 0 had no gradient for it in step 1: p.grad stays None there
+    assert torch.allclose(ret[1][1][-1], torch.full((5,), 3.0)), ret[1][1][-1]
+
+
+def test_shard_batch_takes_the_reference_collate_key_set():
+    """exactly the keys of the reference's collate_fn (data/datasets/kitti.py:421-442, 579-599) - incl. the stacked
+    `depth_map` placeholder, the un-stacked `ori_img` / `info` / `im_file` / `ori_shape` tuples"""
+    B, nbox = 4, 6
+    bi = torch.tensor([0.0, 0.0, 1.0, 2.0, 3.0, 3.0])
+    full = {"img": torch.rand(B, 3, 8, 8), "ori_img": tuple(object() for _ in range(B)), "calib": torch.rand(B, 6),
+            "info": tuple({"img_id": i} for i in range(B)), "cls": torch.zeros(nbox), "bboxes": torch.rand(nbox, 4), "batch_idx": bi,
+            "im_file": tuple(f"{i:06d}.txt" for i in range(B)), "ori_shape": tuple((375, 1242) for _ in range(B)), "ratio_pad": torch.rand(B, 2, 2),
+            "center_2d": torch.rand(nbox, 2), "center_3d": torch.rand(nbox, 2), "size_2d": torch.rand(nbox, 2), "size_3d": torch.rand(nbox, 3),
+            "depth": torch.rand(nbox), "depth_map": torch.empty(B, 1), "mean_sizes": torch.rand(3, 3), "heading_bin": torch.zeros(nbox),
+            "heading_res": torch.rand(nbox), "mixed": torch.zeros(B, dtype=torch.uint8)}
+    for r in range(2):
+        loc = ddp.shard_batch(full, r, 2)
+        assert set(loc) == set(full)
+        assert loc["depth_map"].shape == (2, 1) and loc["ratio_pad"].shape == (2, 2, 2)
+        assert loc["ori_img"] == full["ori_img"][2 * r:2 * r + 2] and loc["info"] == full["info"][2 * r:2 * r + 2]
+        assert loc["ori_shape"] == full["ori_shape"][2 * r:2 * r + 2]
+        assert loc["size_3d"].shape[0] == loc["batch_idx"].numel() == 3

@@ -830,3 +830,129 @@ def test_random_conv_geometries_new_kernels_vs_generic():
             assert torch.equal(stt, ref_st), f"{tag}: BatchNorm partial sums ({which})"
             assert torch.equal(dxx, ref_dx), f"{tag}: dx ({which})"
             assert torch.equal(dww, ref_dw), f"{tag}: dW ({which})"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: every BASELINE configuration produces a bench line; skipped steps; target overflow
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("argv,what", [
+    (["--model", "yolov10l.yaml", "--imgsz", "640", "--batch", "2"], "configs[3] model (L, 2D head)"),
+    (["--model", "yolov10x_3D.yaml", "--weights", "fp8", "--batch", "2"], "configs[4] model (X + 3D head, fp8 weights)"),
+    (["--model", "yolov10m_3D.yaml", "--batch", "2"], "configs[2] model (M + 3D head: non-uniform branches, 1x1 second layer)"),
+], ids=["l2d", "x3d_fp8", "m3d"])
+def test_bench_main_prints_a_line_for_every_baseline_model(argv, what, capsys):
+    """bench.py crashed on the 2D yamls after warm-up (its roofline key assumed the stacked 3D head); no test ran
+    bench.main() past argument parsing.  One step + one warm-up of each non-default BASELINE model through bench.main itself."""
+    import json
+    import bench
+    try:
+        bench.main(argv + ["--steps", "1", "--warmup", "1", "--infer-steps", "1", "--no-cpu-baseline"])
+    finally:
+        y3d.set_weight_quant(None)
+        y3d.set_compute_dtype(torch.bfloat16)
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["metric"] == "train_images_per_sec" and out["value"] > 0 and out["infer_images_per_sec"] > 0, what
+    assert all(v == v and abs(v) < 1e6 for v in out["loss_items"]), out["loss_items"]
+    roof = out["roofline"]
+    assert roof is not None and roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["launches_timed"] >= 1, roof
+    assert out["steps_skipped_nonfinite"] == 0
+
+
+def test_l2d_1280_hires_step_eval_and_postprocess():
+    """BASELINE configs[3] at its own size: YOLOv10-L (2D head), 1280 x 1280, B = 1, bf16 - one training step (finite items and
+    gradients), then eval: 33 600 anchors, and `v10postprocess` (HIP) of the one-to-one output equal to the oracle's postprocess of
+    the SAME maps (scores to fp32 rounding, labels and boxes at the selected anchors exactly)"""
+    from bench import synth_batch
+    from oracle import restate as RS
+    from yolov10_3d_amd.loss import v10postprocess
+    y3d.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    model = y3d.YOLOv10DetectionModel("yolov10l.yaml").to(DEV).train()
+    nc = model.yaml["nc"]
+    batch = synth_batch(1, 1280, 1280, 11, DEV, nc=nc)
+    for _ in range(2):  # the second pass runs on moved running statistics
+        loss, items = model(batch)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+    assert torch.isfinite(items).all(), items
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    with torch.no_grad():
+        y = model(batch["img"])["one2one"][0]
+    assert y.shape == (1, 4 + nc, 160 * 160 + 80 * 80 + 40 * 40) and y.shape[2] == 33600
+    preds = y.permute(0, 2, 1)
+    bx, sc, lab = v10postprocess(preds, 300, nc)
+    pc = preds.float().cpu()
+    bx_o, sc_o, lab_o = RS.postprocess2d(pc, 300, nc)
+    # the selected SCORES are determined (exactly tied scores - frequent among bf16 logits at random init - may come from different
+    # anchors / classes: lowest index first here, library order in torch.topk) ...
+    assert torch.equal(sc.cpu(), sc_o), f"max |score difference| {float((sc.cpu() - sc_o).abs().max()):.3e}"
+    # ... and every detection must be a true (anchor, class) of the map: its box is an anchor's box whose score of that class is the score
+    bxc, scc, labc = bx.cpu()[0], sc.cpu()[0], lab.cpu()[0]
+    for j in range(300):
+        at = (pc[0, :, :4] == bxc[j]).all(-1).nonzero().flatten()
+        assert at.numel() >= 1, f"detection {j}: its box is no anchor's box"
+        assert bool((pc[0, at, 4 + int(labc[j])] == scc[j]).any()), f"detection {j}: score / label do not belong to its box"
+    untied = (sc_o[0, 1:] != sc_o[0, :-1]) & torch.cat(((sc_o[0, 2:] != sc_o[0, 1:-1]), torch.tensor([True])))
+    if bool(untied.any()):  # where the oracle's score has no equal neighbour the pick itself is determined
+        k = untied.nonzero().flatten() + 1
+        assert torch.equal(labc[k], lab_o[0, k].long()) and torch.equal(bxc[k], bx_o[0, k])
+
+
+def test_nonfinite_gradient_norm_skips_the_step_on_the_device():
+    """f1: GradScaler.step's rule (engine/trainer.py:567-572) without a host synchronisation - a NaN / inf gradient leaves the
+    parameters, the momentum / Adam state, AdamW's bias-correction step count and (guarded) the EMA untouched; the next finite step
+    is applied as if the skipped one had not happened"""
+    from yolov10_3d_amd.optim import FusedAdamW, FusedSGD, ModelEMA
+    for cls in (FusedSGD, FusedAdamW):
+        torch.manual_seed(4)
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1)).to(DEV)
+        twin = copy.deepcopy(net)
+        opts = [cls([p for p in m.parameters()], lr=0.05) for m in (net, twin)]
+        ema = ModelEMA(net)
+        grads = [[torch.randn_like(p) for p in net.parameters()] for _ in range(3)]
+
+        def run(m, o, gs, poison=None):
+            for p, g in zip(m.parameters(), gs):
+                p.grad = g.clone()
+            if poison is not None:
+                list(m.parameters())[1].grad[0] = poison
+            o.step(max_norm=10.0)
+            o.zero_grad()
+
+        run(net, opts[0], grads[0])
+        run(twin, opts[1], grads[0])
+        ema.update(net, guard=opts[0].last_norm)
+        e0 = [v.clone() for v in ema.ema.state_dict().values()]
+        for poison in (float("nan"), float("inf")):
+            before = [p.detach().clone() for p in net.parameters()]
+            state = opts[0]._state["flat"].clone()
+            run(net, opts[0], grads[1], poison)   # skipped
+            ema.update(net, guard=opts[0].last_norm)
+            assert float(opts[0].last_norm[2]) == 0.0
+            assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters())), "a skipped step moved the parameters"
+            assert torch.equal(state, opts[0]._state["flat"]), "a skipped step moved the optimizer state"
+            assert all(torch.equal(a, b) for a, b in zip(e0, ema.ema.state_dict().values())), "a guarded EMA update ran after a skipped step"
+        run(net, opts[0], grads[2])
+        run(twin, opts[1], grads[2])
+        assert [float(v) for v in opts[0].last_norm[2:5]] == [1.0, 2.0, 2.0] and [float(v) for v in opts[1].last_norm[2:5]] == [1.0, 2.0, 0.0]
+        for a, b in zip(net.parameters(), twin.parameters()):
+            assert torch.equal(a.detach(), b.detach()), f"{cls.__name__}: the step after a skipped one differs from the never-poisoned twin"
+
+
+def test_pad_targets_overflow_is_reported():
+    """more boxes in one image than the assigner kernels' 64 rows must not be dropped silently"""
+    from yolov10_3d_amd import loss as PL
+    PL.check_target_overflow(wait=True)
+    rows = torch.zeros(70 + 3, 6, device=DEV)
+    rows[:70, 0] = 1  # image 1 has 70 boxes, image 0 has 3
+    rows[:, 2:] = 0.5
+    gt, n_used = PL.pad_targets(rows, 2, 5, (64.0, 64.0))
+    assert int(n_used) == PL.TARGET_CAP and gt.shape == (2, 64, 5)
+    with pytest.raises(y3d.Y3DError, match="70 ground-truth boxes"):
+        PL.check_target_overflow(wait=True)
+    PL.check_target_overflow(wait=True)  # reported once
+    gt, n_used = PL.pad_targets(rows[60:], 2, 5, (64.0, 64.0))  # 10 + 3 boxes: fine
+    PL.check_target_overflow(wait=True)
+    assert int(n_used) == 10

@@ -298,11 +298,23 @@ def test_e2e_tiny2d_vs_reference_golden(dtype, tol):
         check(out["one2many"][0], g["y_eval_o2m"], 2e-3, "eval o2m")
 
 
-@pytest.mark.parametrize("name,S,B", [("yolov10s_3D.yaml", 320, 2), ("yolov10m_3D.yaml", 320, 2), ("yolov10n_3D.yaml", 256, 2), ("yolov10l.yaml", 384, 1)])
-def test_full_size_scales_vs_oracle(name, S, B):
+@pytest.mark.parametrize("name,S,B,quant", [("yolov10s_3D.yaml", 320, 2, None), ("yolov10m_3D.yaml", 320, 2, None), ("yolov10n_3D.yaml", 256, 2, None),
+                                             ("yolov10l.yaml", 384, 1, None), ("yolov10x_3D.yaml", 256, 1, None), ("yolov10b_3D.yaml", 256, 1, None),
+                                             ("yolov10l_3D.yaml", 256, 1, None), ("yolov10x_3D.yaml", 256, 1, "fp8")])
+def test_full_size_scales_vs_oracle(name, S, B, quant):
     """the shipped model yamls at full width (BASELINE configs[1]: S + 3D head, the benchmark's model; configs[2]: M + 3D head with
-    num_scales 2 and 3x3 / 1x1 branch kernels; N + 3D head; configs[3]: L, 2D) on fresh seeded inputs: one training step of the HIP path (exact-fp32 mode) against the CPU oracle restatement
-    with the same weights - loss items within 1e-3 and every parameter's gradient norm within 5e-3"""
+    num_scales 2 and 3x3 / 1x1 branch kernels; N + 3D head; configs[3]: L, 2D; configs[4]: X + 3D head, also with fp8 conv weights - the
+    oracle then runs on `RS.fp8w_state`'s fp8-valued weights; B and L + 3D head) on fresh seeded inputs: one training step of the HIP path
+    (exact-fp32 mode) against the CPU oracle restatement with the same weights - loss items within 1e-3 and every parameter's gradient
+    norm within 5e-3"""
+    y3d.set_weight_quant(quant)
+    try:
+        _full_size_scale_vs_oracle(name, S, B, quant)
+    finally:
+        y3d.set_weight_quant(None)
+
+
+def _full_size_scale_vs_oracle(name, S, B, quant):
     import yaml as _yaml
     import os as _os
     from bench import synth_batch
@@ -327,6 +339,10 @@ def test_full_size_scales_vs_oracle(name, S, B):
     okeys = set(RS.init_state(spec).keys())
     st = {k: v.clone() for k, v in state.items() if k in okeys}
     assert set(st) == okeys
+    if quant == "fp8":
+        st0 = st
+        st = RS.fp8w_state(spec, {k: v.clone() for k, v in st0.items()})
+        assert sum(1 for k in st if not torch.equal(st[k], st0[k])) >= 60, "fp8 mode: the oracle's weights were not quantised"
     for v in st.values():
         if v.is_floating_point():
             v.requires_grad_(True)

@@ -1,3 +1,5 @@
+// ARCHIVED round-2 form of csrc/conv3x3_wide.hip with its -DY3D_PROBE_* / -DY3D_STAGGER ablation branches (tools/probe/build.sh);
+// the product source no longer carries them.
 // bf16 3x3 stride-1 "same" convolution, resident-halo implicit GEMM, PERSISTENT workgroups — the kernel that carries the
 // YOLOv10-3D head (83 % of S-3D forward FLOPs are 3x3 convs at 128 channels per group) and its data gradient.
 //
@@ -37,10 +39,19 @@
 // addresses are therefore recomputed at the issue point from tile scalars (an opaque asm keeps LICM from hoisting them into
 // resident registers) and the weight fragments are refreshed in place.  The build must stay spill-free: a scratch reload in the
 // loop makes the compiler wait vmcnt(0) and drains the DMA pipeline (seen: -25 %).
-#include "common.h"
+#include "../../yolov10-3d_amd/csrc/common.h"
 
 namespace {
 
+#ifdef Y3D_PROBE_TRACE
+__device__ unsigned y3d_probe_trace[2 * 18 * 6];
+#endif
+#ifdef Y3D_PROBE_STAMP
+__device__ unsigned long long y3d_probe_stamps[4096 * 4];
+#define Y3D_WSTAMP(i, v) if (threadIdx.x == 0) y3d_probe_stamps[blockIdx.x * 4 + (i)] v
+#else
+#define Y3D_WSTAMP(i, v)
+#endif
 
 struct W3P {
   const bf16_t* x;
@@ -75,7 +86,11 @@ __device__ __forceinline__ void wvm_n(int n) {
   }
 }
 
+#ifdef Y3D_PROBE_NOLDS
+__device__ __forceinline__ bf16x8_t ldf(const char* p) { unsigned a = (unsigned)(size_t)p; return __builtin_bit_cast(bf16x8_t, make_uint4(a, a, a, a)); }
+#else
 __device__ __forceinline__ bf16x8_t ldf(const char* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
+#endif
 
 // HROLE: this wave streams the halo (waves 0..3), else the weights (waves 4..7).  The two roles run separate, branch-free copies
 // of the loop (same barriers, same MFMAs) so that each keeps compile-time wait counts on its own vmcnt FIFO.
@@ -100,13 +115,22 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
   char* sH = smem;                         // [NHB][HBYTES]
   char* sW = smem + NHB * HBYTES;          // [RD][WB]
   float* red = (float*)(sW + RD * WB);     // [4][128][2]
+#ifdef Y3D_PROBE_TRACE
+  unsigned* trc = (unsigned*)(red + 4 * 128 * 2);  // [2 waves][18 stages][6]
+  int trc_tile = 0;
+#define TRC(i) if (blockIdx.x == 0 && trc_tile == 2 && k < 2 && (wave & 3) == 0 && lane == 0) trc[((wave >> 2) * 18 + k * 9 + t) * 6 + (i)] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define TRC(i)
+#endif
 
   // `wave` and everything derived from it is wave-uniform: scalar registers (the compiler cannot prove threadIdx.x >> 6 uniform)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
+  const int slot = wave & 3;  // DMA issue point of this wave inside its half of the stage (Y3D_STAGGER)
   const int ltid = tid & (LH - 1);
   const int wimg = wp / WPI, wrow0 = (wp % WPI) * 8;
   const int nslab = p.Cg >> 5;             // >= 2 (launcher)
+  Y3D_WSTAMP(0, = __builtin_amdgcn_s_memtime());
 
   // ---- persistent schedule ------------------------------------------------------------------------------------------------------
   const int ntiles = p.G * p.nbt * p.nty * p.ntx * p.ntc;
@@ -159,6 +183,22 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     const int imgoff = NB > 2 ? ((img & 1) ? xsb : 0) + ((img & 2) ? 2 * xsb : 0) : (img ? xsb : 0);
     const unsigned off = (unsigned)(c.b0 * xsb + imgoff + __mul24(yy, (int)p.xsh) + __mul24(xx, (int)p.xsw) + c.g * p.Cg + slab * 32 +
                                     ((s ^ (((hx >> 2) & 1) << 1)) << 3)) * 2u;
+#ifdef Y3D_PROBE_CHEAPADDR  // upper bound of what cheaper halo address arithmetic could give (wrong data)
+    if (rd < HFULL || chunk < HCH)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
+                                               (unsigned)(l * 16 + rd * 4096 + slab * 64), 0, 0, 0);
+    return;
+#endif
+#ifdef Y3D_PROBE_CONTIG  // the full address arithmetic, kept live, but a contiguous (wrong) address in the load: isolates memory locality
+    {
+      unsigned keep = inb ? off : OOB;
+      asm volatile("" ::"v"(keep));
+      if (rd < HFULL || chunk < HCH)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
+                                                 (unsigned)(l * 16 + rd * 4096 + slab * 64), 0, 0, 0);
+      return;
+    }
+#endif
     if (rd < HFULL || chunk < HCH)  // lanes past the end of the last (partial) round must not write LDS
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + bufo + (rd * LH + wave * 64) * 16), 16,
                                                inb ? off : OOB, 0, 0, 0);
@@ -217,6 +257,7 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     wvm<2 * (D - 2)>();  // taps 0, 1
   }
   __builtin_amdgcn_s_barrier();
+  Y3D_WSTAMP(1, = __builtin_amdgcn_s_memtime());
 
   int gs = 0;   // slabs retired: ring slot of (slab, tap) = (9 gs + tap) % 4 = (gs + tap) % 4
   // halo buffers as rotating byte offsets: current slab, next slab, the one being streamed into (== next when NHB == 2)
@@ -253,46 +294,94 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
       const int wslab = last ? 0 : k + 1;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
+        TRC(0);
         // ---- issue (halo role): at the top of the stage.  The LDS-DMA engine of a CU moves ~1 KB per ~40 cycles and the issuing
         // wave is held meanwhile (measured: 250-450 cycles per instruction when all eight waves issue together), so the two waves
         // of a SIMD issue at DIFFERENT times: the halo wave here, while its partner runs half 0's MFMAs; the weight wave between
         // the halves, while this one computes --------------------------------------------------------------------------------------
+#if !defined(Y3D_PROBE_NODMA) && !defined(Y3D_STAGGER)
         if (HROLE) {
+#ifndef Y3D_PROBE_NOHALO
           __builtin_amdgcn_sched_barrier(0);  // confine the address arithmetic to the top of the stage, where the live set is smallest
           halo_stage(htile, hs, hb_tgt, t);
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#endif
+        TRC(1);
         // ---- half 0: pixel rows 0..3 while rows 4..7 of this tap are fetched --------------------------------------------------------
         load_b(fb[1], hb_cur, t, 1);
+#ifdef Y3D_STAGGER
+        // The four halo waves (one per SIMD) issue their DMA instructions at FOUR different points of half 0 - before MFMA group
+        // `slot` = wave & 3 - and the four weight waves likewise inside half 1: eight instructions arriving together queue behind
+        // each other in the CU's one LDS-DMA path and hold every issuing wave for 450-570 cycles of a 1500-cycle stage (probe trace);
+        // spread over the stage each finds the path nearly free.
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if (HROLE && ct == slot) {
+            __builtin_amdgcn_sched_barrier(0);
+            halo_stage(htile, hs, hb_tgt, t);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ct][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[0][i], acc[ct][i], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
+#else
         __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together and ahead of the partner wave's VALU / DMA issue (+2 %)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+#ifdef Y3D_PROBE_NOMFMA
+            asm volatile("" ::"v"(fa[ct]), "v"(fb[0][i]));
+#else
             acc[ct][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[0][i], acc[ct][i], 0, 0, 0);
+#endif
           }
         __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- half 1: rows 4..7 while the first fragments of the next stage are fetched (its tap was published one barrier ago);
         // the weight fragments are refreshed IN PLACE, each right behind the last MFMA that reads it (no second buffer: the
         // 128 accumulators leave no room for one) ------------------------------------------------------------------------------------
+        TRC(2);
         __builtin_amdgcn_sched_barrier(0);  // keep half 1's fragment loads out of half 0: both sets live at once would spill
+#if !defined(Y3D_PROBE_NODMA) && !defined(Y3D_STAGGER)
         if (!HROLE) {
+#ifndef Y3D_PROBE_NOWEIGHT
           __builtin_amdgcn_sched_barrier(0);
           const int t2 = t + D;
           if (t2 < 9) issue_w(cur, k, t2, (kr + t2) & 3);
           else issue_w(wtile, wslab, t2 - 9, (kr + t2) & 3);
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#endif
         const bool pre = t < 8 || !last;
         if (t < 8) load_b(fb[0], hb_cur, t + 1, 0); else if (!last) load_b(fb[0], hb_nxt, 0, 0);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
+#ifdef Y3D_STAGGER
+          if (!HROLE && ct == slot) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int t2 = t + D;
+            if (t2 < 9) issue_w(cur, k, t2, (kr + t2) & 3);
+            else issue_w(wtile, wslab, t2 - 9, (kr + t2) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+#ifdef Y3D_PROBE_NOMFMA
+            asm volatile("" ::"v"(fa[ct]), "v"(fb[1][i]));
+#else
             acc[ct][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], fb[1][i], acc[ct][4 + i], 0, 0, 0);
+#endif
           }
           if (pre) fa[ct] = load_a1((kr + t + 1) & 3, ct);
         }
+        TRC(3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- retire ----------------------------------------------------------------------------------------------------------------
         if (HROLE) {
@@ -306,7 +395,9 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
           else if (t == 0 && k == 0 && tolerate == NST / 2) wvm<2 + NST / 2>();
           else wvm<2>();
         }
+        TRC(4);
         __builtin_amdgcn_s_barrier();
+        TRC(5);
       }
     }
 
@@ -356,7 +447,11 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
             v[c2 * 4 + j] = u;
             if (EPI == 0) { ssum[h][c2 * 4 + j] += u; ssq[h][c2 * 4 + j] += u * u; }
           }
+#ifdef Y3D_PROBE_NOEPI
+        if (pok && cok[h] && v[0] == 123.456f) {
+#else
         if (pok && cok[h]) {
+#endif
           *(uint4*)(dst + h * 32) = Chunk<bf16_t>::pack(v);
         }
       }
@@ -390,6 +485,9 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
         }
       }
     }
+#ifdef Y3D_PROBE_TRACE
+    ++trc_tile;
+#endif
     tolerate = st_wave;
     cur = nx;
     {
@@ -398,6 +496,11 @@ __device__ __forceinline__ void wide_body(const W3P& p) {
     }
   }
   wvm<0>();  // the dead loads past the last tile must land before the workgroup retires
+#ifdef Y3D_PROBE_TRACE
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 2 * 18 * 6) y3d_probe_trace[tid] = trc[tid];
+#endif
+  Y3D_WSTAMP(3, = __builtin_amdgcn_s_memtime());
 }
 
 template <int TH, int EPI>

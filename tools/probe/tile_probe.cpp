@@ -1,7 +1,7 @@
 // Stand-alone timing probe for the resident-halo 3x3 kernel on the headline shape (16 groups of 128->128 @80x80, B=32, bf16).
 // Built in variants (-DY3D_PROBE_NODMA / _NOMFMA / _NOLDS) to see which resource bounds the loop.  Not part of the library.
 #include "../../yolov10-3d_amd/csrc/conv3x3_tile.hip"
-#include "../../yolov10-3d_amd/csrc/conv3x3_wide.hip"
+#include "conv3x3_wide_v2_probe.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

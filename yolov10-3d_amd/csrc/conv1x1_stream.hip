@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
         }
         // N % 4 == 0 (launcher): the four channels of a lane are all inside or all outside
         const pw_u32x2 u = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
-        __builtin_amdgcn_raw_buffer_store_b64(u, ry, (m < p.M) & (co < p.N) ? (unsigned)(m * (int)p.ysw + co) * 2u : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u, ry, ((m < p.M) & (co < p.N)) ? (unsigned)(m * (int)p.ysw + co) * 2u : OOB, 0, 0);
       }
     }
     hist[NS - 2] += TC * TP;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
           if (inb) { ssum[a][j] += v[j]; ssq[a][j] += v[j] * v[j]; }
         }
         const sm_u32x2 u = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
-        __builtin_amdgcn_raw_buffer_store_b64(u, ry, inb & (co < p.Cout) ? (pix + co) * 2u : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u, ry, (inb & (co < p.Cout)) ? (pix + co) * 2u : OOB, 0, 0);
       }
     }
     buf ^= 1;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
           const int ci = ci0 + a * 16 + 4 * lq;
           const f32x4_t v = acc[r][cls][a];
           const s2_u32x2 u = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
-          __builtin_amdgcn_raw_buffer_store_b64(u, rx, inb & (ci < p.Cin) ? (pix + ci) * 2u : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u, rx, (inb & (ci < p.Cin)) ? (pix + ci) * 2u : OOB, 0, 0);
         }
       }
     buf ^= 1;

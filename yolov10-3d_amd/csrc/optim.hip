@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void mt_sqnorm_kernel(const long* __restrict__
   if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-// out[0] = total L2 norm, out[1] = min(1, max_norm / (norm + 1e-6))
+// out[0] = total L2 norm, out[1] = min(1, max_norm / (norm + 1e-6)), out[2] = 1 if the norm is finite else 0 (the update kernels
+// are no-ops for that step: GradScaler.step's skip, engine/trainer.py:569-572), out[3] += out[2] (number of steps applied so far),
+// out[4] += 1 - out[2] (number of steps skipped)
 __global__ __launch_bounds__(256) void mt_clip_kernel(const float* __restrict__ partials, int n, float max_norm, float* __restrict__ out) {
   __shared__ double sh[256];
   double s = 0.0;
@@ -49,8 +51,12 @@ __global__ __launch_bounds__(256) void mt_clip_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) {
     float norm = (float)sqrt(sh[0]);
     float c = max_norm / (norm + 1e-6f);
+    const bool ok = isfinite(norm);
     out[0] = norm;
     out[1] = c < 1.f ? c : 1.f;
+    out[2] = ok ? 1.f : 0.f;
+    out[3] += ok ? 1.f : 0.f;
+    out[4] += ok ? 0.f : 1.f;
   }
 }
 
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(256) void mt_sgd_kernel(const long* __restrict__ pp
   float* b = (float*)bptr[t] + off;
   long n = sizes[t] - off;
   if (n > chunk) n = chunk;
+  if (clip && clip[2] == 0.f) return;  // non-finite gradient norm: this step is skipped on every rank (the norm is that of the reduced buffer)
   const float c = clip ? clip[1] : 1.f, l = lr[t], w = wd[t];
   for (long i = threadIdx.x; i < n; i += 256) {
     float pv = p[i];
@@ -113,6 +120,13 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const long* __restrict__ 
   float* v = (float*)vptr[t] + off;
   long n = sizes[t] - off;
   if (n > chunk) n = chunk;
+  if (clip) {
+    if (clip[2] == 0.f) return;  // skipped step (non-finite gradient norm): state and step count stay
+    // the step count of the bias corrections is the number of APPLIED steps, which only the device knows
+    const double tstep = (double)clip[3];
+    bc1 = (float)(1.0 - pow((double)beta1, tstep));
+    bc2s = (float)sqrt(1.0 - pow((double)beta2, tstep));
+  }
   const float c = clip ? clip[1] : 1.f, l = lr[t], w = wd[t];
   const float step_size = l / bc1, decay = 1.f - l * w, w1 = 1.f - beta1, w2 = 1.f - beta2;
   for (long i = threadIdx.x; i < n; i += 256) {
@@ -130,7 +144,8 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const long* __restrict__ 
 // reference's state_dict lists under several keys -- the aliased one-to-one head branches -- is updated once per key)
 __global__ __launch_bounds__(256) void mt_ema_kernel(const long* __restrict__ eptr, const long* __restrict__ mptr, const long* __restrict__ sizes,
                                                      const int* __restrict__ reps, const int* __restrict__ ctensor, const int* __restrict__ coff,
-                                                     int chunk, float d, float omd) {
+                                                     int chunk, float d, float omd, const float* __restrict__ guard) {
+  if (guard && guard[2] == 0.f) return;  // the optimizer step this update follows was skipped: the model did not move
   const int t = ctensor[blockIdx.x];
   const long off = (long)coff[blockIdx.x] * chunk;
   float* e = (float*)eptr[t] + off;
@@ -198,10 +213,10 @@ int y3d_mt_adamw(const int64_t* param_ptrs, const int64_t* grad_ptrs, const int6
 }
 
 int y3d_mt_ema(const int64_t* ema_ptrs, const int64_t* model_ptrs, const int64_t* sizes, const int* reps, const int* chunk_tensor,
-               const int* chunk_off, int nchunks, int chunk, float decay, float one_minus_decay, void* stream) {
+               const int* chunk_off, int nchunks, int chunk, float decay, float one_minus_decay, const float* guard, void* stream) {
   Y3D_CHECK(nchunks >= 1 && chunk >= 256, "mt_ema: empty chunk table");
   hipLaunchKernelGGL(mt_ema_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)ema_ptrs, (const long*)model_ptrs,
-                     (const long*)sizes, reps, chunk_tensor, chunk_off, chunk, decay, one_minus_decay);
+                     (const long*)sizes, reps, chunk_tensor, chunk_off, chunk, decay, one_minus_decay, guard);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __re
 }
 
 // utils/loss.py:795-810 `preprocess`: ragged per-box rows [batch_idx | cls | xywh in [0,1] | ...] -> (B, cap, width) zero-padded per image
-// in order of appearance, boxes scaled to pixels and converted to xyxy; *n_used = largest per-image box count (device side: the
-// reference sizes the tensor with a host-side counts.max()).  One block per image.
+// in order of appearance, boxes scaled to pixels and converted to xyxy; n_used[0] = min(largest per-image box count, cap), n_used[1] =
+// the largest count itself (device side: the reference sizes the tensor with a host-side counts.max()).  One block per image.
 __global__ __launch_bounds__(256) void pad_targets_kernel(const float* __restrict__ rows, int nbox, int width, float* __restrict__ out, int cap,
                                                           float sx, float sy, int* __restrict__ n_used) {
   __shared__ int smax[256];
@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256) void pad_targets_kernel(const float* __restric
     if (threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0 && smax[0] > 0) atomicMax(n_used, smax[0]);
+  if (threadIdx.x == 0 && smax[0] > 0) {
+    atomicMax(n_used, min(smax[0], cap));  // rows the assigner walks
+    atomicMax(n_used + 1, smax[0]);        // the true largest count: > cap means boxes were dropped (the host raises on it)
+  }
 }
 
 struct LossW { float loss2d, cls, depth, offset3d, size3d, heading; };
@@ -331,7 +334,7 @@ int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, floa
                     void* stream) {
   Y3D_CHECK(B >= 1 && cap >= 1 && width >= 5 && nbox >= 0, "pad_targets: B, cap >= 1, width >= 5 (cls + box + ...)");
   hipStream_t st = (hipStream_t)stream;
-  Y3D_HIP(hipMemsetAsync(n_used, 0, sizeof(int), st));
+  Y3D_HIP(hipMemsetAsync(n_used, 0, 2 * sizeof(int), st));
   hipLaunchKernelGGL(pad_targets_kernel, dim3(B), dim3(256), 0, st, rows, nbox, width, out, cap, scale_x, scale_y, n_used);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;

@@ -22,7 +22,9 @@ import torch.distributed as dist
 
 # keys of the collated batch dict (reference data/datasets/kitti.py:421-442, collate_fn :579-599)
 PER_BOX_KEYS = ("cls", "bboxes", "center_2d", "size_2d", "center_3d", "size_3d", "depth", "heading_bin", "heading_res")
-PER_IMAGE_KEYS = ("img", "calib", "mixed", "im_file", "ori_shape", "resized_shape", "ratio_pad", "info")
+# per-image entries: stacked tensors (`depth_map` is a (B, 1) placeholder unless depth maps are loaded, kitti.py:409-420) and the
+# tuples of B python objects collate_fn leaves un-stacked (`ori_img`, `info`, `im_file`, `ori_shape`)
+PER_IMAGE_KEYS = ("img", "calib", "mixed", "im_file", "ori_shape", "resized_shape", "ratio_pad", "info", "depth_map", "coord_range", "ori_img")
 REPLICATED_KEYS = ("mean_sizes",)
 
 
@@ -65,8 +67,12 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
         elif k in PER_IMAGE_KEYS:
             assert len(v) == B, f"shard_batch: per-image entry {k!r} has {len(v)} rows for {B} images"
             out[k] = v[lo:hi]
-        elif k in REPLICATED_KEYS or not torch.is_tensor(v):
+        elif k in REPLICATED_KEYS:
             out[k] = v
+        elif not torch.is_tensor(v):
+            # an un-stacked per-image sequence (collate_fn keeps non-tensor values as tuples of length B) is sliced; anything else
+            # (scalars, strings, config objects) is replicated
+            out[k] = v[lo:hi] if isinstance(v, (list, tuple)) and len(v) == B else v
         else:
             raise KeyError(f"shard_batch: do not know how to split batch entry {k!r} (add it to PER_BOX_KEYS / PER_IMAGE_KEYS / REPLICATED_KEYS)")
     return out
@@ -94,7 +100,14 @@ class FlatGradReducer:
     (trainer.py:401-402).
     Why not torch DDP: its autograd hooks copy each of the ~570 gradient tensors into a bucket view one by one (+17 % step time
     measured at one rank); the gather is one launch per bucket at HBM rate.
-    `overlap=False` (env Y3D_DDP_OVERLAP=0): everything is gathered and reduced in `finish()`, after the backward."""
+    `overlap=False` (env Y3D_DDP_OVERLAP=0): everything is gathered and reduced in `finish()`, after the backward.
+
+    Contract: ONE `finish()` per optimizer step, gradients cleared with `zero_grad(set_to_none=True)` in between
+    (after `finish()` `p.grad` IS the all-reduced slot: a backward that accumulated into it would be reduced a second time; the
+    next launch raises when it sees that).  Gradient accumulation (reference: `accumulate = nbs / batch` micro-steps, trainer.py:383-386,
+    DDP `no_sync`) runs the first micro-steps under `with reducer.no_sync():` - no hook counts, nothing is launched, autograd adds
+    into `p.grad` as usual - and the last one outside it, followed by `finish()`.  A parameter without a gradient in this step has
+    its slot ZEROED before the collective, whatever an earlier step left there (another rank may own a gradient for it)."""
 
     CHUNK = 16384
 
@@ -134,12 +147,27 @@ class FlatGradReducer:
         self.timing = timing
         self.comm = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._tabs = {}
+        self._dirty = [False] * len(self.params)  # slot i holds something other than zeros
         self._reset()
         self._hooks = []
         if overlap:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.last_times = None
+        self._sync = True
+
+    def no_sync(self):
+        """context manager for the non-final micro-steps of gradient accumulation (torch DDP's `no_sync`)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = prev
+        return cm()
 
     # ---- per-step state ------------------------------------------------------------------------------------------
     def _reset(self):
@@ -152,6 +180,8 @@ class FlatGradReducer:
 
     def _make_hook(self, i):
         def hook(p):
+            if not self._sync:
+                return  # accumulation micro-step: the gradient stays local in p.grad
             if self._ready[i]:
                 return  # accumulated twice in one backward (shared parameter): the bucket was counted once
             self._ready[i] = True
@@ -201,11 +231,20 @@ class FlatGradReducer:
 
     def _launch(self, b):
         a, e = self.buckets[b]
-        idx, grads = [], []
+        idx, grads, stale = [], [], []
         for i in range(a, e):
             g = self.params[i].grad
-            if g is None or g.data_ptr() == self.views[i].data_ptr():
-                continue  # no gradient (slot stays zero), or accumulated in place into the slot already
+            if g is None:
+                if self._dirty[i]:
+                    stale.append(i)  # a gradient of an earlier step is still in the slot: this rank contributes zero now
+                continue
+            self._dirty[i] = True
+            if g.data_ptr() == self.views[i].data_ptr():
+                # p.grad is still the slot finish() re-pointed it at: this backward accumulated into an all-reduced sum, which the
+                # collective below would reduce a second time
+                raise RuntimeError("FlatGradReducer: a gradient was accumulated into its already all-reduced slot - clear gradients "
+                                   "with zero_grad(set_to_none=True) after every finish(), and run the non-final micro-steps of "
+                                   "gradient accumulation under reducer.no_sync()")
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.float().contiguous()
             idx.append(i)
@@ -220,6 +259,9 @@ class FlatGradReducer:
             with torch.cuda.stream(self.comm):
                 # the side stream is ONE timeline: gather(b), all-reduce(b), gather(b+1), ...  (with RCCL `wait()` only orders the
                 # stream behind the collective; host-staged backends block the host here, which a rehearsal tolerates)
+                for i in stale:
+                    self.views[i].zero_()
+                    self._dirty[i] = False
                 if idx:
                     self._gather(idx, grads)
                 t0 = t1 = None
@@ -234,6 +276,9 @@ class FlatGradReducer:
                     self._events.append((ev, t0, t1, hi - lo))
             self._keep.append(grads)  # the sources stay alive until finish() has ordered the compute stream behind the copies
         else:
+            for i in stale:
+                self.views[i].zero_()
+                self._dirty[i] = False
             if idx:
                 self._gather(idx, grads)
             if multi:
@@ -242,6 +287,8 @@ class FlatGradReducer:
     def finish(self):
         """Call after backward, before the optimizer step: launch the remaining buckets, wait for the collectives (the compute
         stream waits, not the host), p.grad = slot views.  -> the flat buffer"""
+        if not self._sync:
+            raise RuntimeError("FlatGradReducer.finish() inside no_sync(): run the last micro-step's backward outside the context")
         while self._next < len(self.buckets):
             self._launch(self._next)
             self._next += 1

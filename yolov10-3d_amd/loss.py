@@ -22,19 +22,54 @@ from ._lib import Y3DError, lib
 from .modules import make_anchors
 
 
-def pad_targets(rows, B, width, scale_xy, cap=64):
+_OVERFLOW_PENDING = []  # (event, pinned int32[1], cap) of pad_targets launches whose per-image box count has not been looked at yet
+TARGET_CAP = 64  # rows per image the assigner kernels take (tal_loss3d.hip / tal_loss2d.hip)
+
+
+def check_target_overflow(wait=False):
+    """Raise Y3DError if a `pad_targets` launch met an image with more boxes than its capacity (its surplus boxes were dropped).
+    The count comes back through a pinned host word behind an event: `pad_targets` polls the finished ones at its next call (the
+    training step keeps running without a host synchronisation and the error surfaces a step or two late); wait=True synchronises
+    on all of them (validators, tests)."""
+    keep = []
+    for ev, host, cap in _OVERFLOW_PENDING:
+        if wait:
+            ev.synchronize()
+        if not ev.query():
+            keep.append((ev, host, cap))
+            continue
+        n = int(host[0])
+        if n > cap:
+            _OVERFLOW_PENDING[:] = keep
+            raise Y3DError(f"pad_targets: an image of a recent batch has {n} ground-truth boxes, the assigner kernels take at most {cap} per "
+                           f"image (KITTI's max_objs is 50); its last {n - cap} boxes were not trained on")
+    _OVERFLOW_PENDING[:] = keep
+
+
+def pad_targets(rows, B, width, scale_xy, cap=TARGET_CAP):
     """utils/loss.py:795-810 on the HIP kernel `y3d_pad_targets`: ragged rows (nbox, 1+width) -> (B, cap, width) + the device-side
     largest per-image box count.  The reference sizes the padded tensor with a host-side `counts.max()`; here the capacity is fixed
     (`cap`, the assigner kernels' limit of 64 rows; KITTI's max_objs is 50, data/datasets/kitti.py:23) and the count stays on the
-    device, so the step has no host synchronisation.  -> (gt (B, cap, width) fp32, n_used (1,) int32)"""
+    device, so the step has no host synchronisation.  An image with more than `cap` boxes (crowded 2D data, mosaics) is NOT trained
+    on silently truncated targets: the true count travels to a pinned host word asynchronously and `check_target_overflow` raises
+    (ADVICE round 2).  -> (gt (B, cap, width) fp32, n_used (1,) int32: min(largest count, cap))"""
     if not rows.is_cuda:
         raise Y3DError("pad_targets runs on the HIP kernel of tal_loss3d.hip: the batch must live on a HIP device (no CPU fallback)")
+    check_target_overflow()
     rows = rows.float().contiguous()
     out = torch.empty(B, cap, width, dtype=torch.float32, device=rows.device)
-    n_used = torch.empty(1, dtype=torch.int32, device=rows.device)
+    n_used = torch.empty(2, dtype=torch.int32, device=rows.device)  # [min(count, cap), true count]
     lib().pad_targets(rows.data_ptr(), rows.shape[0], width, B, cap, float(scale_xy[0]), float(scale_xy[1]), out.data_ptr(), n_used.data_ptr(),
                       ops.stream())
-    return out, n_used
+    if not torch.cuda.is_current_stream_capturing():
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(n_used[1:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _OVERFLOW_PENDING.append((ev, host, cap))
+        if len(_OVERFLOW_PENDING) > 64:  # a caller that never lets the stream drain: look now
+            check_target_overflow(wait=True)
+    return out, n_used[:1]
 
 
 def _flatten_maps(feats):

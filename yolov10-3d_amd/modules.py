@@ -604,7 +604,10 @@ class v10Detect3d(nn.Module):
 
 
 class Detect(nn.Module):
-    """reference head.py:22-109 (YOLOv8 detect head; base of v10Detect)"""
+    """reference head.py:22-109 (YOLOv8 detect head; base of v10Detect).
+    Restrictions against the reference: the eval decode (`inference`) is the HIP kernel `y3d_head2d_decode` - head
+    maps on a HIP device and reg_max == 16 (the value every shipped yaml uses; the constructor fixes it as the reference does);
+    anything else raises instead of falling back to a host formulation."""
 
     dynamic = False
     export = False

@@ -83,13 +83,15 @@ def concat_buffer(x, C, H=None, W=None):
     if not PLACEMENT or not x.is_cuda or C % ce(dtype) != 0:
         return None
     buf = nhwc_empty(x.shape[0], C, x.shape[2] if H is None else H, x.shape[3] if W is None else W, dtype, x.device)
-    _CONCAT_BASE[buf.data_ptr()] = C
+    _CONCAT_BASE[buf.data_ptr()] = (C, buf)
     return buf
 
 
 # addresses of the live concat buffers: ConcatFn only trusts "already in place" for slices of a buffer made by concat_buffer (a PSA
 # block concatenates a slice of its cv1 output with a NEW tensor: that slice has the right strides too, and filling "its" buffer would
 # overwrite the other half, which the backward still needs).  An entry dies with its ConcatFn; a model forward starts from none.
+# The entry HOLDS its buffer: while an address is in the table the memory behind it cannot be freed and handed to another tensor, so
+# "address + channel count match" cannot be a coincidence (a buffer nobody consumed lives until the next reset_placement).
 _CONCAT_BASE = {}
 
 
@@ -416,7 +418,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     else:
         xin = to_nhwc(x, dtype)
     sb, sh, sw = s3(xin)
-    y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+    y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev) if (dw or training or res_mode) else None  # pre-BatchNorm tensor (the eval fast path has none)
     part = None
     if dw:
         if Cout % c != 0:
@@ -449,9 +451,10 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                     cache.clear()
                     cache[key] = hit
             wp, ss = hit
+            ye = out_tensor(B, Cout, Ho, Wo, dtype, dev)  # a pending placement (C2f / SPPF / Concat slot) is honoured in eval too
             L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), int(act),
-                                y.data_ptr(), Cout, Ho, Wo, Cout, g, k, k, s, p, st)
-            return y, None, None
+                                ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st)
+            return ye, None, None
         if pack_cache and training and PACK_CACHE:
             wp = PACK_FWD.lookup(w32, w32.data_ptr(), (Cout, Cin // g, Cg_pad, k * k, k * k * Cg_pad, dt), dtype, ver[0] if ver is not None else None)
         else:
@@ -482,18 +485,17 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
 
 
-def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None, wver=None):
+def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
     """-> dx, dW (fp32 OIHW), dgamma, dbeta, dres.  dx_range=(lo, hi): only output channels lo..hi feed dx
     (the one-to-one head sees a detached input, reference head.py:820)."""
     L = lib()
     xin, w32, y, stats, rr = saved
     stem = cfg[-1] == "stem"
     B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, act = cfg[:17]
-    wver = cfg[17]
     if not training:
         raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
     if pre is not None:  # (dy, dgb): the BatchNorm part was done by the caller (FusedConvBNProjFn)
-        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range, wver)
+        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range)
     dt = code(dtype)
     st = stream()
     dev = dz.device
@@ -517,11 +519,12 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None, w
                        dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
     if res_mode == 1:
         dres = dz
-    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, wver)
+    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range)
 
 
-def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, wver=None):
-    """data and weight gradients of the conv given dy (gradient wrt its pre-BatchNorm output)"""
+def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
+    """data and weight gradients of the conv given dy (gradient wrt its pre-BatchNorm output); cfg[17] = version token of the weights
+    as the forward packed them"""
     L = lib()
     xin, w32, y, stats, rr = saved
     stem = cfg[-1] == "stem"
@@ -668,14 +671,14 @@ class FusedConvBNActFn(torch.autograd.Function):
         if m.training:
             for c in stack.convs:
                 c._nbt_pending += 1
-        ctx.cfg, ctx.couts, ctx.dx_range, ctx.wver = cfg, stack.couts, dx_range, stack.ver[0]
+        ctx.cfg, ctx.couts, ctx.dx_range = cfg, stack.couts, dx_range
         if saved is not None:
             ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range, wver=ctx.wver)
+        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range)
         dWs, dgs, dbs, off = [], [], [], 0
         for co in ctx.couts:
             dWs.append(dW[off:off + co])
@@ -961,7 +964,6 @@ class FusedConvBNProjFn(torch.autograd.Function):
         ws, bs = params[npar:npar + n], params[npar + n:]
         y, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum, bn_apply=False,
                                      ver=stack.ver)
-        ctx.wver = stack.ver[0]
         if m.training:
             for c in stack.convs:
                 c._nbt_pending += 1
@@ -1037,7 +1039,7 @@ class FusedConvBNProjFn(torch.autograd.Function):
         else:
             dz = nhwc_empty(B, Ct, H, W, dtype, dev)
             L.proj_group_bwd_data(dt, n, cin, dout.data_ptr(), dout.stride(3), c_off, c_w, c_co, dz.data_ptr(), Ct, P, st)
-            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None, wver=ctx.wver)
+            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None)
         dWs, dgs, dbs_s, off = [], [], [], 0
         for co in ctx.couts_stack:
             dWs.append(dW[off:off + co])
@@ -1078,7 +1080,7 @@ class ConcatFn(torch.autograd.Function):
             if (PLACEMENT and x.dtype == dtype and x.is_cuda and is_nhwc(x) and x.stride(3) == tot and x.stride(2) == W * tot
                     and x.stride(0) == H * W * tot):
                 base = x.data_ptr() - off * esz
-                if out is None and _CONCAT_BASE.get(base) == tot:
+                if out is None and _CONCAT_BASE.get(base, (None, None))[0] == tot:
                     del _CONCAT_BASE[base]
                     out = torch.as_strided(x, (B, tot, H, W), x.stride(), x.storage_offset() - off)
                     assert out.data_ptr() == base

@@ -104,7 +104,7 @@ class FusedSGD:
             "sizes": i64(sizes), "ctensor": torch.tensor(ct, dtype=torch.int32, device=dev), "coff": torch.tensor(co, dtype=torch.int32, device=dev),
             "bptr": i64([bufs[i][0].data_ptr() for i in active]),
             "bptr2": i64([bufs[i][1].data_ptr() for i in active]) if self.NSTATE > 1 else None, "partials": torch.empty(len(ct), dtype=torch.float32, device=dev),
-            "norm_clip": torch.empty(2, dtype=torch.float32, device=dev), "pkey": None, "gkey": None,
+            "norm_clip": old["norm_clip"] if old is not None else torch.zeros(5, dtype=torch.float32, device=dev), "pkey": None, "gkey": None,
             "lr": torch.tensor([lr_all[i] for i in active], dtype=torch.float32, device=dev),
             "wd": torch.tensor([wd_all[i] for i in active], dtype=torch.float32, device=dev),
             "hkey": [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups],
@@ -140,7 +140,10 @@ class FusedSGD:
 
     @torch.no_grad()
     def step(self, max_norm: float | None = 10.0):
-        """clip (when max_norm is given) + update; self.last_norm holds the device tensor [total_norm, clip_coef]"""
+        """clip (when max_norm is given) + update; self.last_norm holds the device tensor [total_norm, clip_coef, finite flag, steps
+        applied, steps skipped].  A step whose gradient norm is inf / NaN is skipped ON THE DEVICE (no host synchronisation): parameters,
+        momentum / Adam state and AdamW's bias-correction step count stay - torch.cuda.amp.GradScaler.step's rule, engine/trainer.py:
+        567-572.  Under ddp.FlatGradReducer the norm is that of the all-reduced buffer, so every rank takes the same decision."""
         st = self._tables()
         L, s = lib(), ops.stream()
         clip = None
@@ -234,7 +237,10 @@ class ModelEMA:
         return self._tab
 
     @torch.no_grad()
-    def update(self, model):
+    def update(self, model, guard=None):
+        """guard: FusedSGD / FusedAdamW `.last_norm` of the optimizer step this update follows - the update is then skipped on the
+        device when that step was (the reference's line runs unconditionally, engine/trainer.py:574-575, and re-applies the decay to
+        an unchanged model; guard=None keeps that arithmetic)"""
         if not self.enabled:
             return
         self.updates += 1
@@ -255,7 +261,7 @@ class ModelEMA:
             tb["mptr"], tb["mkey"] = torch.tensor(mkey, dtype=torch.int64, device=dev), mkey
         ops.bump_param_epoch()
         lib().mt_ema(tb["eptr"].data_ptr(), tb["mptr"].data_ptr(), tb["sizes"].data_ptr(), tb["reps"].data_ptr(), tb["ct"].data_ptr(),
-                     tb["co"].data_ptr(), tb["n"], CHUNK, float(d), float(1 - d), ops.stream())
+                     tb["co"].data_ptr(), tb["n"], CHUNK, float(d), float(1 - d), guard.data_ptr() if guard is not None else None, ops.stream())
 
     def update_attr(self, model, include=(), exclude=("process_group", "reducer")):
         """utils/torch_utils.py:445-448 / copy_attr :342-349"""
