@@ -64,8 +64,9 @@ def synth_batch(B, H, W, seed, device, nc=3):
 
 def conv_key_flops(key):
     """algorithmic FLOPs of one launch of an ops._timed conv key: 2 * B * Ho * Wo * Cout * (Cin / g) * k * k"""
-    _, _, B, H, W, Cin, Cout, k, s, g = key
-    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    _, _, B, H, W, Cin, Cout, k, s, g = key[:10]
+    pad = key[10] if len(key) > 10 else k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     return 2.0 * B * Ho * Wo * Cout * (Cin // g) * k * k
 
 
@@ -160,7 +161,8 @@ def main(argv=None):
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--phases", action="store_true", help="per-phase device times (backward / all-reduce / optimizer) in the JSON line (default for N > 1)")
     ap.add_argument("--no-phases", action="store_true", help="N > 1: no per-phase events")
-    ap.add_argument("--graph", action="store_true", help="replay the eval forward + postprocess from a captured hipGraph (inference leg)")
+    ap.add_argument("--infer-mode", default="graph", choices=["graph", "eager"],
+                    help="inference leg: replay the eval forward + postprocess from one captured hipGraph per batch (default), or launch eagerly")
     args = ap.parse_args(argv)
     if args.gpus > 1 and not args.no_phases:
         args.phases = True  # four event records per step; the exposed all-reduce time is what a scaling run is read for
@@ -282,30 +284,70 @@ def main(argv=None):
     assert torch.isfinite(items).all(), f"non-finite loss items {items}"
     train_ips = world * B * args.steps / dt_s
 
-    # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190)
+    # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190: "Speed: ... ms per image").  The forward
+    # is ~200 launches of 3-150 us: enqueued eagerly the host is the bound (tools/eval_audit.py), so the timed loop replays ONE captured
+    # hipGraph per batch (yolov10-3d_amd/graph.py; --infer-mode eager keeps the launch-by-launch loop); the eager rate is reported next to it
     model.eval()
-    infer_ips = None
+    infer_ips = infer_eager_ips = None
+    infer_mode = args.infer_mode
+    roof_infer = None
     nc = model.yaml["nc"]
 
-    def infer_once():
-        y = model(batch["img"])["one2one"][0]
+    def infer_once(img):
+        y = model(img)["one2one"][0]
         if is3d:
             return v10_3Dpostprocess(y.permute(0, 2, 1), 50, nc)
         return v10postprocess(y.permute(0, 2, 1), 300, nc)
 
-    with torch.no_grad():
-        for _ in range(2 if args.infer_steps > 0 else 0):
-            infer_once()
+    def timed_infer(fn, n):
         sync()
         t1 = time.perf_counter()
-        for _ in range(args.infer_steps):
-            infer_once()
+        for _ in range(n):
+            fn()
         sync()
         ti = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(ti, op=dist.ReduceOp.MAX)
-        infer_ips = world * B * args.infer_steps / float(ti) if args.infer_steps > 0 else None
-    log(f"infer: {infer_ips:.1f} images/s" if infer_ips else "infer: skipped")
+        return world * B * n / float(ti)
+
+    if args.infer_steps > 0:
+        with torch.no_grad():
+            for _ in range(2):
+                infer_once(batch["img"])
+            # dominant eval kernel, timed launch by launch with HIP events in an eager pass (a graph replay has no per-kernel events)
+            ekeys = {}
+            ops.TIMER = ops.KernelTimer(lambda key: ekeys.setdefault(key, 0) is None)
+            infer_once(batch["img"])
+            ops.TIMER = None
+            ecands = [k for k in ekeys if k[0] == "conv_eval"]
+            ekey = max(ecands, key=lambda k: (conv_key_flops(k), k)) if ecands else None
+            if ekey is not None:
+                ops.TIMER = ops.KernelTimer(lambda key: key == ekey)
+                for _ in range(3):
+                    infer_once(batch["img"])
+                etimes = ops.TIMER.results().get(ekey, [])
+                ops.TIMER = None
+                if etimes:
+                    ems = sum(etimes) / len(etimes)
+                    eflops = conv_key_flops(ekey)
+                    peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+                    roof_infer = {"bound": "mfma", "kernel": "eval conv + folded BatchNorm + SiLU, %dx%d s%d %d->%d (%d groups) on %d maps of %dx%d, pad %d (largest eval launch by FLOPs)"
+                                  % (ekey[7], ekey[7], ekey[8], ekey[5], ekey[6], ekey[9], ekey[2], ekey[3], ekey[4], ekey[10]),
+                                  "achieved": round(eflops / (ems * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                  "frac": round(eflops / (ems * 1e-3) / 1e12 / peak, 4), "launches_timed": len(etimes), "avg_launch_ms": round(ems, 4),
+                                  "flops_per_launch": eflops, "traffic": None}
+            infer_eager_ips = timed_infer(lambda: infer_once(batch["img"]), args.infer_steps)
+            infer_ips = infer_eager_ips
+            if infer_mode == "graph":
+                try:
+                    from yolov10_3d_amd.graph import GraphedForward
+                    gf = GraphedForward(infer_once, batch["img"])
+                    gf(gf.inputs[0])
+                    infer_ips = timed_infer(lambda: gf(gf.inputs[0]), args.infer_steps)
+                except Exception as e:  # a capture failure must not cost the run its train number
+                    log(f"hipGraph capture of the eval forward failed ({type(e).__name__}: {e}); reporting the eager rate")
+                    infer_mode = "eager"
+    log(f"infer: {infer_ips:.1f} images/s ({infer_mode}; eager {infer_eager_ips:.1f})" if infer_ips else "infer: skipped")
 
     if rank == 0:
         res = timer.results().get(k1_key, []) if k1_key is not None else []
@@ -344,7 +386,8 @@ def main(argv=None):
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": args.backend if dist.is_initialized() else None,
             "steps_skipped_nonfinite": int(opt.last_norm[4]) if opt.last_norm is not None else None,
-            "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None,
+            "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None, "infer_mode": infer_mode if infer_ips else None,
+            "infer_images_per_sec_eager": round(infer_eager_ips, 2) if infer_eager_ips else None, "roofline_infer": roof_infer,
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -941,3 +941,54 @@ def test_fused_sgd_matches_torch():
         check(o_my.last_norm[0:1], n_ref.reshape(1), 1e-5, "grad norm")
         for p, q in zip(ref, mine):
             check(q, p, 1e-6, f"param after step {step}")
+
+
+def test_graphed_eval_forward_replays_the_eager_forward():
+    """yolov10-3d_amd/graph.py: the eval forward + postprocess captured into one hipGraph gives the eager forward's outputs bit for bit,
+    on new inputs too (copied into the static buffer), and re-captures after the parameters moved (a training step bumps
+    ops.PARAM_EPOCH: the capture holds the addresses of the packed / folded eval constants of the OLD state)"""
+    from bench import synth_batch
+    from yolov10_3d_amd import ops
+    from yolov10_3d_amd.graph import GraphedForward
+    from yolov10_3d_amd.loss import v10_3Dpostprocess
+    from yolov10_3d_amd.optim import build_optimizer
+    y3d.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(2)
+    model = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml").to(DEV)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.uniform_(-0.2, 0.2)
+    model.eval()
+    imgs = [synth_batch(2, 256, 256, s, DEV)["img"] for s in (1, 2)]
+
+    def fwd(img):
+        y, maps = model(img)["one2one"]
+        return (y,) + v10_3Dpostprocess(y.permute(0, 2, 1), 50, 3)
+
+    with torch.no_grad():
+        eager = [[t.clone() for t in fwd(im)] for im in imgs]
+    g = GraphedForward(fwd, imgs[0])
+    for im, ref in zip(imgs + imgs[:1], eager + eager[:1]):
+        out = g(im)
+        torch.cuda.synchronize()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    assert g.captures == 1
+    # parameters move -> the next call re-captures and matches the eager forward of the NEW state
+    model.train()
+    opt = build_optimizer(model)
+    batch = synth_batch(2, 256, 256, 5, DEV)
+    loss, _ = model(batch)
+    loss.backward()
+    opt.step(max_norm=10.0)
+    model.eval()
+    with torch.no_grad():
+        ref = [t.clone() for t in fwd(imgs[1])]
+    out = g(imgs[1])
+    torch.cuda.synchronize()
+    assert g.captures == 2
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert not torch.equal(ref[0], eager[1][0]), "the training step did not change the eval output: the test would not see a stale capture"

@@ -9,44 +9,64 @@
 
 namespace {
 
-// block-wide arg-max of (value desc, index asc) over `n` LDS values, K times, excluding earlier winners by overwriting them
+// K times the block-wide arg-max of (value desc, index asc) over `n` LDS values, earlier winners excluded by overwriting them with -inf.
+// Every thread keeps the best of ITS strided subset in registers; a round is one wave reduction by shuffles, one LDS hand-off between
+// the (<= 16) waves - double-buffered, so ONE barrier per winner - and a rescan of the winner's subset by its owner thread only
+// (the first form rescanned all n values and took two barriers per winner: 175 us for the 6 400 cells of the stride-8 level).
+// sv / si: at least 2 * (blockDim.x / 64) entries each.
 __device__ void block_topk(float* vals, int n, int K, int* out_idx, float* out_val, float* sv, int* si) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int a = tid; a < n; a += nt) {
+    const float v = vals[a];
+    if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
+  }
   for (int j = 0; j < K; ++j) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int a = threadIdx.x; a < n; a += blockDim.x) {
-      float v = vals[a];
-      if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
-    }
-    // arg-max inside the wave by shuffles, across the (<= 16) waves through LDS: two barriers per winner instead of nine
+    float wv = bv;
+    int wi = bi;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const float v2 = __shfl_xor(bv, off);
-      const int i2 = __shfl_xor(bi, off);
-      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+      const float v2 = __shfl_xor(wv, off);
+      const int i2 = __shfl_xor(wi, off);
+      if (v2 > wv || (v2 == wv && i2 < wi)) { wv = v2; wi = i2; }
     }
-    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    float* svj = sv + (j & 1) * nw;
+    int* sij = si + (j & 1) * nw;
+    if (lane == 0) { svj[wave] = wv; sij[wave] = wi; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < nw; ++w)
-        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-      out_idx[j] = bi < n ? bi : 0;
-      if (out_val) out_val[j] = bv;
-      if (bi < n) vals[bi] = -INFINITY;  // -inf entries can only be re-selected when fewer than K finite values exist
+    float gv = svj[0];
+    int gi = sij[0];
+    for (int w = 1; w < nw; ++w) {
+      const float v2 = svj[w];
+      const int i2 = sij[w];
+      if (v2 > gv || (v2 == gv && i2 < gi)) { gv = v2; gi = i2; }
     }
-    __syncthreads();
+    if (tid == 0) {
+      out_idx[j] = gi < n ? gi : 0;
+      if (out_val) out_val[j] = gv;
+    }
+    if (gi < n && gi % nt == tid) {  // the owner retires the winner and finds the next best of its subset
+      vals[gi] = -INFINITY;          // -inf entries can only be re-selected when fewer than K finite values exist
+      bv = -INFINITY;
+      bi = 0x7fffffff;
+      for (int a = tid; a < n; a += nt) {
+        const float v = vals[a];
+        if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
+      }
+    }
   }
+  __syncthreads();  // out_idx / out_val (often LDS) are complete for every thread
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void topk_cells_kernel(const T* __restrict__ cls, long psw, int HW, int nc, int K, int* __restrict__ out) {
+__global__ __launch_bounds__(1024) void topk_cells_kernel(const T* __restrict__ cls, long psw, int HW, int nc, int K, int* __restrict__ out) {
   extern __shared__ float sm[];  // [HW] + reduction scratch
   float* vals = sm;
   float* sv = sm + HW;
   int* si = (int*)(sv + 256);
   const int b = blockIdx.x;
-  for (int a = threadIdx.x; a < HW; a += 256) {
+  for (int a = threadIdx.x; a < HW; a += blockDim.x) {
     const T* p = cls + ((long)b * HW + a) * psw;
     float m = TT<T>::ld(p);
     for (int c = 1; c < nc; ++c) m = fmaxf(m, TT<T>::ld(p + c));
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256) void kde_fusion_kernel(const float* __restrict
 
 // preds y (B, C, A) fp32 with `nc` score rows first: reg (B,K,C-nc), scores (B,K), labels (B,K) int64
 // hi-res maps, stage 1: block (seg, b) scores the anchors of its segment (max over classes) in LDS and keeps their K best
-__global__ __launch_bounds__(256) void postprocess_seg_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first, int seglen,
+__global__ __launch_bounds__(1024) void postprocess_seg_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first, int seglen,
                                                               float* __restrict__ scratch) {
   extern __shared__ float sm[];
   float* vals = sm;            // [seglen]
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(256) void postprocess_seg_kernel(const float* __res
   const int s0 = boxes_first ? C - nc : 0;
   const int a0 = seg * seglen;
   const int n = min(seglen, A - a0);
-  for (int a = threadIdx.x; a < n; a += 256) {
+  for (int a = threadIdx.x; a < n; a += blockDim.x) {
     float m = yb[(long)s0 * A + a0 + a];
     for (int c = 1; c < nc; ++c) m = fmaxf(m, yb[(long)(s0 + c) * A + a0 + a]);
     vals[a] = m;
@@ -351,13 +371,13 @@ __global__ __launch_bounds__(256) void postprocess_seg_kernel(const float* __res
   block_topk(vals, n, kk, top, tv, sv, si);
   float* cv = scratch + ((long)b * nseg + seg) * K;
   int* ci = (int*)(scratch + (long)gridDim.y * nseg * K) + ((long)b * nseg + seg) * K;
-  for (int i = threadIdx.x; i < K; i += 256) {
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
     cv[i] = i < kk ? tv[i] : -INFINITY;
     ci[i] = i < kk ? a0 + top[i] : 0;
   }
 }
 
-__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first,
+__global__ __launch_bounds__(1024) void postprocess_kernel(const float* __restrict__ y, int A, int C, int nc, int K, int boxes_first,
                                                           float* __restrict__ reg, float* __restrict__ scores, long* __restrict__ labels,
                                                           float* __restrict__ scratch, int nseg) {
   extern __shared__ float sm[];
@@ -378,9 +398,9 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
   const int nr = C - nc;
   if (scratch) {
     const float* cv = scratch + (long)b * ncand;
-    for (int a = threadIdx.x; a < ncand; a += 256) vals[a] = cv[a];
+    for (int a = threadIdx.x; a < ncand; a += blockDim.x) vals[a] = cv[a];
   } else {
-    for (int a = threadIdx.x; a < A; a += 256) {
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
       float m = yb[(long)s0 * A + a];
       for (int c = 1; c < nc; ++c) m = fmaxf(m, yb[(long)(s0 + c) * A + a]);
       vals[a] = m;
@@ -390,17 +410,17 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
   block_topk(vals, ncand, K, top, nullptr, sv, si);
   if (scratch) {  // candidate position -> anchor index (positions are ordered by segment, then by rank: ties keep the lowest anchor first)
     const int* ci = (const int*)(scratch + (long)gridDim.x * ncand) + (long)b * ncand;
-    for (int i = threadIdx.x; i < K; i += 256) top[i] = ci[top[i]];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) top[i] = ci[top[i]];
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < K * nc; i += 256) sc2[i] = yb[(long)(s0 + i % nc) * A + top[i / nc]];
+  for (int i = threadIdx.x; i < K * nc; i += blockDim.x) sc2[i] = yb[(long)(s0 + i % nc) * A + top[i / nc]];
   __syncthreads();
   block_topk(sc2, K * nc, K, top2, val2, sv, si);
-  for (int i = threadIdx.x; i < K; i += 256) {
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
     scores[(long)b * K + i] = val2[i];
     labels[(long)b * K + i] = top2[i] % nc;
   }
-  for (int i = threadIdx.x; i < K * nr; i += 256) {
+  for (int i = threadIdx.x; i < K * nr; i += blockDim.x) {
     int j = i / nr, c = i - j * nr;
     reg[((long)b * K + j) * nr + c] = yb[(long)(r0 + c) * A + top[top2[j] / nc]];
   }
@@ -485,10 +505,10 @@ int y3d_topk_cells(int dtype, const void* cls, int64_t psw, int B, int HW, int n
   hipStream_t st = (hipStream_t)stream;
   if (dtype == Y3D_BF16) {
     (void)hipFuncSetAttribute((const void*)topk_cells_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(topk_cells_kernel<bf16_t>, dim3(B), dim3(256), sm, st, (const bf16_t*)cls, (long)psw, HW, nc, K, out_idx);
+    hipLaunchKernelGGL(topk_cells_kernel<bf16_t>, dim3(B), dim3(HW >= 2048 ? 1024 : 256), sm, st, (const bf16_t*)cls, (long)psw, HW, nc, K, out_idx);
   } else {
     (void)hipFuncSetAttribute((const void*)topk_cells_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(topk_cells_kernel<float>, dim3(B), dim3(256), sm, st, (const float*)cls, (long)psw, HW, nc, K, out_idx);
+    hipLaunchKernelGGL(topk_cells_kernel<float>, dim3(B), dim3(HW >= 2048 ? 1024 : 256), sm, st, (const float*)cls, (long)psw, HW, nc, K, out_idx);
   }
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
@@ -573,12 +593,12 @@ int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det
     Y3D_CHECK((long)nseg * max_det * 2 <= A && (size_t)(seglen + 512 + 2 * max_det) * 4 <= 160 * 1024, "v10_postprocess: %d anchors with max_det %d", A, max_det);
     size_t sm1 = (size_t)(seglen + 512 + 2 * max_det) * 4;
     (void)hipFuncSetAttribute((const void*)postprocess_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(postprocess_seg_kernel, dim3(nseg, B), dim3(256), sm1, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, seglen, scratch);
+    hipLaunchKernelGGL(postprocess_seg_kernel, dim3(nseg, B), dim3(1024), sm1, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, seglen, scratch);
   }
   size_t sm = (size_t)((fits ? A : nseg * max_det) + 512 + max_det * (nc + 3)) * 4;
   Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: max_det * nc = %d does not fit LDS", max_det * nc);
   (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch,
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3((fits ? A : nseg * max_det) >= 2048 ? 1024 : 256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch,
                      nseg);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;

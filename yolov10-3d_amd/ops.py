@@ -364,6 +364,31 @@ def conv_bn_act_eval(x, w, gamma, beta, rm, rv, k, s, p, g, act, eps, cache=None
     return z
 
 
+def _eval_consts(cache, kind, w32, g32, b32, rm, rv, ver, dtype, k, g, Cin_g, Cg_pad, Cout, eps):
+    """eval-mode constants of one conv, cached in `cache` (a dict owned by the module / stack) until a parameter or buffer changes:
+    the packed weights (kind "dense": K-contiguous compute-dtype rows; "dw": tap-major fp32 rows) and the folded BatchNorm
+    (scale, shift) pair.  A steady-state eval forward launches neither packing nor bn_eval_scale kernels."""
+    L, st, dev = lib(), stream(), w32.device
+    vkey = ver[1] if ver is not None else (w32._version, g32._version, b32._version, rm._version, rv._version)
+    key = (kind, PARAM_EPOCH, w32.data_ptr(), g32.data_ptr(), rm.data_ptr(), vkey, dtype, k, g, Cg_pad, Cout, float(eps))
+    hit = cache.get(key) if cache is not None else None
+    if hit is None:
+        if kind == "dw":
+            wp = _f32(k * k * Cout, dev)
+            L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+        else:
+            wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
+            L.pack_weight_fwd(code(dtype), w32.data_ptr(), wp.data_ptr(), Cout, Cin_g, Cg_pad, k, k, st)
+        ss = _f32(2 * Cout, dev).view(2, Cout)
+        L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, ss[0].data_ptr(), ss[1].data_ptr(), st)
+        hit = (wp, ss, w32)  # w32 kept alive: its address is part of the key
+        if cache is not None:  # owned by the module / stack, so it dies with the tensors it describes
+            for old in [q for q in cache if q[1] != PARAM_EPOCH]:
+                del cache[old]
+            cache[key] = hit
+    return hit[0], hit[1]
+
+
 def _timed(key, launch):
     if TIMER is not None:
         TIMER.bracket(key, launch)
@@ -401,10 +426,17 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
             L.stem_im2col_u8(dt, xs.data_ptr(), hwc, xcol.data_ptr(), B, H, W, Ho, Wo, st)
         else:
             L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
-        wcol = torch.zeros(Cout, 32, dtype=torch.float32, device=dev)
-        wcol[:, :27] = w32.detach().permute(0, 2, 3, 1).reshape(Cout, 27)  # column (r*3+q)*3+ci
+        wkey = ("stemcol", PARAM_EPOCH, w32.data_ptr(), ver[0] if ver is not None else w32._version)
+        wcol = cache.get(wkey) if (cache is not None and not training) else None
+        if wcol is None:
+            wcol = torch.zeros(Cout, 32, dtype=torch.float32, device=dev)
+            wcol[:, :27] = w32.detach().permute(0, 2, 3, 1).reshape(Cout, 27)  # column (r*3+q)*3+ci
+            if cache is not None and not training:  # eval: the im2col form of the stem weight is a constant of the forward
+                for old in [q for q in cache if q[1] != PARAM_EPOCH]:
+                    del cache[old]
+                cache[wkey] = wcol
         z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache,
-                                     pack_cache=False, quant=False)  # wcol is a temporary (built from the already quantised stem weight)
+                                     pack_cache=False, quant=False)  # wcol is built from the already quantised stem weight
         return z, (cfg + ("stem",) if cfg is not None else None), saved
     dw = g > 1 and g == Cin and g == Cout
     # ---- input: NHWC compute dtype; the stem (Cin=3) is channel-padded while converting from NCHW fp32
@@ -426,8 +458,12 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         nblk = L.dw_blocks(M)
         if training:
             part = _f32(nblk * Cout * 2, dev)
-        wp = _f32(k * k * Cout, dev)
-        L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+        ss_eval = None
+        if training:
+            wp = _f32(k * k * Cout, dev)
+            L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
+        else:
+            wp, ss_eval = _eval_consts(cache, "dw", w32, g32, b32, rm, rv, ver, dtype, k, g, 1, 1, Cout, eps)
         L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
                        part.data_ptr() if training else None, st)
     else:
@@ -435,27 +471,20 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         if training:
             part = _f32(nblk * Cout * 2, dev)
         Cg_pad = Cin_k // g
+        ss_eval = None
+        if not training:
+            wp, ss_eval = _eval_consts(cache, "dense", w32, g32, b32, rm, rv, ver, dtype, k, g, Cin // g, Cg_pad, Cout, eps)
         if not training and not res_mode:
             # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor; the packed
             # weights and the scale/shift pair are cached until a parameter / buffer is modified in place or re-pointed
-            vkey = ver[1] if ver is not None else (w32._version, g32._version, b32._version, rm._version, rv._version)
-            key = (PARAM_EPOCH, w32.data_ptr(), g32.data_ptr(), rm.data_ptr(), vkey, dtype, k, g, Cg_pad, Cout, float(eps))
-            hit = cache.get(key) if cache is not None else None
-            if hit is None:
-                wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
-                L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
-                ss = _f32(2 * Cout, dev).view(2, Cout)
-                L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, ss[0].data_ptr(), ss[1].data_ptr(), st)
-                hit = (wp, ss)
-                if cache is not None:  # owned by the module / stack, so it dies with the tensors it describes
-                    cache.clear()
-                    cache[key] = hit
-            wp, ss = hit
             ye = out_tensor(B, Cout, Ho, Wo, dtype, dev)  # a pending placement (C2f / SPPF / Concat slot) is honoured in eval too
-            L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), int(act),
-                                ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st)
+            _timed(("conv_eval", dt, B, H, W, Cin_k, Cout, k, s, g, p),
+                   lambda: L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss_eval[0].data_ptr(), ss_eval[1].data_ptr(),
+                                               int(act), ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st))
             return ye, None, None
-        if pack_cache and training and PACK_CACHE:
+        if not training:
+            pass  # eval with a residual: conv (cached packed weights) + one BatchNorm / SiLU / residual pass below
+        elif pack_cache and training and PACK_CACHE:
             wp = PACK_FWD.lookup(w32, w32.data_ptr(), (Cout, Cin // g, Cg_pad, k * k, k * k * Cg_pad, dt), dtype, ver[0] if ver is not None else None)
         else:
             wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
@@ -463,13 +492,16 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
                lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
                                     k, k, s, p, part.data_ptr() if training else None, st))
-    stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
     if training:
+        stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
         bump_param_epoch()  # bn_finalize updates the running statistics in place
         L.bn_finalize(part.data_ptr(), nblk, Cout, M, g32.data_ptr(), b32.data_ptr(), eps, momentum, rm.data_ptr(), rv.data_ptr(),
                       stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
     else:
-        L.bn_eval_scale(Cout, g32.data_ptr(), b32.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
+        stats = None  # eval: the cached (scale, shift) pair
+        if not bn_apply:  # the fused consumer reads rows 2 / 3 of a statistics tensor
+            stats = torch.zeros(6, Cout, dtype=torch.float32, device=dev)
+            stats[2:4].copy_(ss_eval)
     if not bn_apply:  # the consumer applies BatchNorm + activation itself (FusedConvBNProjFn): hand back the pre-BN tensor
         cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
         return y, cfg, (xin, w32, y, stats, None)
@@ -478,7 +510,8 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     if res_mode:
         rr = to_nhwc(res, dtype, dense=True)
         assert rr.shape == z.shape, "residual shape mismatch"
-    L.bn_act_fwd(dt, y.data_ptr(), Cout, stats[2].data_ptr(), stats[3].data_ptr(), int(act), res_mode,
+    sc_t, sh_t = (stats[2], stats[3]) if training else (ss_eval[0], ss_eval[1])
+    L.bn_act_fwd(dt, y.data_ptr(), Cout, sc_t.data_ptr(), sh_t.data_ptr(), int(act), res_mode,
                  rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), z.stride(3), M, Cout, st)
     # [17]: version token of the weights as packed (stacked views / fp8 shadows carry their identity outside the tensor's own counter)
     cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
