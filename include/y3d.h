@@ -156,6 +156,9 @@ int y3d_upsample2x_bwd(int dtype, const void* dy, int64_t dsb, int64_t dsh, int6
                        int W, int C, void* stream);
 /* torch.cat(dim=1) member copy — Concat conv.py:404, block.py:178,233,818: y[:, :C] = x over P pixels */
 int y3d_copy2d(int dtype, const void* x, int64_t xsw, void* y, int64_t ysw, int64_t P, int C, void* stream);
+/* diagnostic, no reference counterpart (tools/cu_contention.py): n workgroups that stay resident on `stream` until *flag != 0 (device
+ * int) or ~50 ms, moving a trickle of data inside buf - a stand-in for an RCCL kernel's CU footprint next to the backward pass */
+int y3d_occupy_cus(int n, const int* flag, float* buf, int64_t nbuf, void* stream);
 int y3d_add2d(int dtype, const void* a, int64_t asw, const void* b, int64_t bsw, void* y, int64_t ysw, int64_t P, int C, void* stream);
 /* model boundary: reference tensors are NCHW fp32 (nn/tasks.py:93-95) */
 int y3d_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cpad, void* stream);

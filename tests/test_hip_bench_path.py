@@ -83,6 +83,7 @@ BENCH_SHAPES = [
     (192, 320, 1, 24, 24, 3),       # Cn % 128 = 64, Cg = 192 (X-model widths)
     (96, 80, 1, 16, 40, 5),         # Cn % 128 = 80 (multiple of 16 only), ragged x tiles
     (1152, 1152, 2, 40, 40, 2),     # groups of 576 -> 576 (M-3D fused layer widths)
+    # (the P5 comment above predates the ragged-height path: 20 rows run as three 8-row tiles of the persistent kernel)
     # narrow body layers: conv3x3_small.hip (all nine taps' weights resident, forward + flipped-tap data gradient)
     (64, 64, 1, 80, 80, 4),         # the 64 -> 64 Bottleneck convs at 80x80
     (32, 32, 1, 160, 160, 2),       # 32 -> 32 at 160x160 (64-byte K slabs)
@@ -115,6 +116,36 @@ def test_conv_bench_shapes_bit_exact_on_integer_operands(shape):
     dW_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1, groups=g)
     assert float(dW_ref.abs().max()) < 2 ** 24
     assert torch.equal(dW, dW_ref), f"weight gradient: {int((dW != dW_ref).sum())} of {dW.numel()} differ"
+
+
+def test_conv_roofline_shape_real_valued_within_derived_bound():
+    """the integer tests above are exact only on {0, +-1} operands.  The roofline launch's geometry (16 groups
+    of 128 -> 128 @80x80; B = 4 keeps the host reference affordable, the persistent kernels still run 800 tiles) with REAL-valued
+    bf16 operands against an fp64 host convolution, each output held to a bound derived from the arithmetic: fp32 accumulation of K
+    exact products (<= K * 2^-24 * sum|x||w|, doubled for the split partial sums) plus ONE bf16 rounding of the result (2^-8
+    relative, round to nearest even); the weight gradient has no output rounding (fp32)."""
+    Cin = Cout = 2048
+    g, H, W, B = 16, 80, 80, 4
+    gen = torch.Generator().manual_seed(11)
+    bfr = lambda t: t.bfloat16().float()
+    pre = torch.randn(B, Cin, H, W, generator=gen)
+    x = bfr(pre * torch.sigmoid(pre))                       # a post-SiLU activation
+    w = bfr(torch.randn(Cout, Cin // g, 3, 3, generator=gen) * 0.03)
+    dy = bfr(torch.randn(B, Cout, H, W, generator=gen) * 0.1)
+    y3d.set_compute_dtype(torch.bfloat16)
+    y, _, dx, dW = _conv_abi(x, w, g, dy)
+    K = 9 * (Cin // g)
+    eps32 = 2.0 ** -24
+    for name, got, ref, mag, kk, rounded in (
+            ("forward", y, F.conv2d(x.double(), w.double(), padding=1, groups=g), F.conv2d(x.abs(), w.abs(), padding=1, groups=g), K, True),
+            ("data gradient", dx, torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1, groups=g),
+             torch.nn.grad.conv2d_input(x.shape, w.abs(), dy.abs(), padding=1, groups=g), K, True),
+            ("weight gradient", dW, torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1, groups=g),
+             torch.nn.grad.conv2d_weight(x.abs(), w.shape, dy.abs(), padding=1, groups=g), B * H * W, False)):
+        bound = 2.0 * kk * eps32 * mag.double() + (2.0 ** -8 * ref.abs() if rounded else 0.0) + 1e-30
+        excess = ((got.double() - ref).abs() / bound).max()
+        assert float(excess) <= 1.0, f"{name}: an output is {float(excess):.2f} x its derived error bound away from the fp64 convolution"
+        del ref, mag
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -203,7 +234,8 @@ def test_bf16_e2e_tiny3d_no_worse_than_reference_autocast():
     print(f"[bf16 yardstick] e2e_tiny3d_s: head maps hip {dh:.2e} / ref-autocast {dr:.2e}; loss items (max-norm) hip {ih:.2e} / ref-autocast {ir:.2e}")
     assert dh <= RATIO * dr, f"head maps: HIP bf16 {dh:.3e} vs reference autocast {dr:.3e}"
     # the assigner is discrete: a flipped positive moves an item by O(10 %) in the reference's own 16-bit run too (it is 17 % off here)
-    assert ih <= max(RATIO * ir, 0.3), f"loss items: HIP bf16 {ih:.3e} vs reference autocast {ir:.3e}"
+    # (round 2 allowed max(1.5 x reference, 0.3); the floor is dropped where 1.5 x the reference's own distance is the tighter bound)
+    assert ih <= RATIO * ir, f"loss items: HIP bf16 {ih:.3e} vs reference autocast {ir:.3e}"
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -767,7 +799,7 @@ def test_random_conv_geometries_new_kernels_vs_generic():
     import os
     import random
     rnd = random.Random(int(os.environ.get("Y3D_SWEEP_SEED", "7")))
-    count = int(os.environ.get("Y3D_SWEEP_COUNT", "36"))
+    count = int(os.environ.get("Y3D_SWEEP_COUNT", "100"))
     L = y3d.lib()
     y3d.set_compute_dtype(torch.bfloat16)
     chans = [8, 16, 24, 32, 40, 48, 64, 72, 96, 128, 136, 160, 192, 256, 264, 320, 384, 512]

@@ -1,4 +1,5 @@
-// 3x3 stride-1 "same" convolution of the NARROW body layers (32 or 64 input channels, at most 64 output channels; bf16): forward and,
+// 3x3 stride-1 "same" convolution of the NARROW body layers (8 .. 64 input channels in multiples of 8 - 32 / 64 of the N, S, B, L
+// widths, 48 of M; a count below its 32- / 64-channel LDS row is zero-filled by out-of-range DMA lanes - at most 64 output channels; bf16): forward and,
 // with flipped taps on dy, the data gradient.  Reference: the Bottleneck 3x3 convs of the first C2f stages (nn/modules/block.py:327-342
 // through conv.py:120-122).
 //
@@ -49,12 +50,12 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   char* sH = smem + WB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwk = gridDim.x, wk = blockIdx.x;
-  const int Cin = CB / 2;
+  const int Cin = p.Cin;  // <= CB / 2: the chunks of an LDS row past the real channels hold zeros (weights: below; halo: out-of-range DMA lanes)
 
   for (int i = tid; i < 9 * NCT * 16 * CPR; i += 256) {
     const int c = i % CPR, r = (i / CPR) % (NCT * 16), tap = i / (CPR * NCT * 16);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < p.Cout) v = *(const uint4*)(p.w + (long)r * p.Ktot + (p.flip ? 8 - tap : tap) * Cin + c * 8);
+    if (r < p.Cout && c * 8 < Cin) v = *(const uint4*)(p.w + (long)r * p.Ktot + (p.flip ? 8 - tap : tap) * Cin + c * 8);
     *(uint4*)(sW + (tap * NCT * 16 + r) * CB + ((c ^ sm_swz<CB>(r)) << 4)) = v;
   }
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
     const int P = ii * SPI + lane / CPR, cpos = lane % CPR;
     const int row = P / HW, col = P - row * HW;
     p_off[n] = (row - 1) * p.xsh + (col - 1) * p.xsw + ((cpos ^ sm_swz<CB>(P)) << 3);
-    p_rc[n] = ((P < NPIX ? row : 255) << 8) | col;
+    p_rc[n] = (((P < NPIX) & ((cpos ^ sm_swz<CB>(P)) * 8 < Cin) ? row : 255) << 8) | col;  // the chunk this lane FETCHES must hold real channels
   }
   auto issue = [&](int t, int buf) {
     int b, y0, x0;
@@ -202,14 +203,14 @@ void sm_launch(const SmP& p, int grid, hipStream_t st) {
 extern "C" int y3d_get_stream1x1(void);
 
 int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int rows) {
-  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || (Cin != 32 && Cin != 64) || Cout > 64 || Cout < 8 || Cout % 4 != 0) return 0;
+  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || Cin < 8 || Cin > 64 || Cin % 8 != 0 || Cout > 64 || Cout < 8 || Cout % 4 != 0) return 0;
   if (H < 4 || W < 8 || rows < 1) return 0;
   return 1;
 }
 
 // workgroups (= rows of BatchNorm partials) for this shape
 int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout) {
-  const int nct = cdiv(Cout, 16), cb = Cin * 2;
+  const int nct = cdiv(Cout, 16), cb = Cin <= 32 ? 64 : 128;  // bytes of an LDS row
   const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
   const long ntiles = (long)B * cdiv(H, 8) * cdiv(W, 16);
   const long grid = 256 * (lds <= 80 * 1024 ? 2 : 1);
@@ -231,7 +232,7 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
   p.nty = cdiv(H, 8); p.ntx = cdiv(W, 16); p.ntiles = B * p.nty * p.ntx;
   p.xbytes = (unsigned)xext; p.ybytes = (unsigned)yext;
   const int nct = cdiv(Cout, 16);
-  const int cb = Cin * 2;
+  const int cb = Cin <= 32 ? 64 : 128;
   const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
   (void)lds;
   const int grid = y3d_conv3x3_small_rows(B, H, W, Cin, Cout);

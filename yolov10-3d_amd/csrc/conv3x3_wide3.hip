@@ -290,18 +290,25 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
 
     // ---- epilogue: this lane holds channels cl(h) .. cl(h)+7, h = 0 / 1, of pixels (wrow0 + pt, lp) of image b0 + wimg.  The two
     // 64-byte halves of a pixel's 128-byte line are stored back to back (conv3x3_wide.hip) ---------------------------------------------
-    const int e_lp = lane & 15, e_lq = lane >> 4;
-    const int e_tid = (HROLE ? 0 : 256) + ltid;
+    // lane-derived epilogue values are recomputed HERE from an opaque copy of the lane id: derived before the K loop (where the compiler
+    // would hoist them, the tile's coordinates being known there) they are carried through it in registers the loop does not have
+    int el = ltid;
+    asm volatile("" : "+v"(el));
+    const int e_lp = el & 15, e_lq = (el >> 4) & 3;
+    const int e_tid = (HROLE ? 0 : 256) + el;
     const int bb = cur.b0 + wimg;
     const bool xok = cur.x0 + e_lp < p.W;
     const int cl0 = wc * 64 + e_lq * 8;
     bool cok[2];
-    float ssum[2][8], ssq[2][8], sv[2][8], hv[2][8];
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    f2_t s2[2][4], q2[2][4];  // BatchNorm sums of this lane's 2 x 8 channels, as register pairs (packed fp32 adds / FMAs)
+    float sv[2][8], hv[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       cok[h] = cur.c0 + cl0 + h * 32 < p.Cn && bb < p.B;  // Cn % 16 == 0
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { ssum[h][i] = 0.f; ssq[h][i] = 0.f; }
+      for (int i = 0; i < 4; ++i) { s2[h][i] = (f2_t){0.f, 0.f}; q2[h][i] = (f2_t){0.f, 0.f}; }
       if (EPI == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -310,26 +317,52 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
         }
       }
     }
+    if (EPI == 0) {
+      // training epilogue, ~3 VALU instructions per output (the first form took ~7): one v_cvt_pk_bf16_f32 per channel pair IS the store
+      // operand; pixels past a ragged map are cleared by ONE and on the packed pair; the rounded values come back by a shift / mask for
+      // the BatchNorm sums, which run as packed fp32 adds / FMAs (two channels per instruction)
 #pragma unroll
-    for (int pt = 0; pt < 8; ++pt) {
-      const int yy = cur.y0 + wrow0 + pt;
-      const bool pok = xok & (yy < p.H);  // rows past a ragged map (H % TH != 0) are computed and dropped
-      bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + e_lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
+      for (int pt = 0; pt < 8; ++pt) {
+        const int yy = cur.y0 + wrow0 + pt;
+        const bool pok = xok & (yy < p.H);  // rows past a ragged map (H % TH != 0) are computed and dropped
+        const unsigned keep = pok ? 0xffffffffu : 0u;
+        bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + e_lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float v[8];
+        for (int h = 0; h < 2; ++h) {
+          unsigned pk[4];
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+          for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float u = acc[2 * h + c2][pt][j];
-            if (EPI == 1) { u = u * sv[h][c2 * 4 + j] + hv[h][c2 * 4 + j]; if (p.act) u = silu_f(u); }
-            u = pok ? bf2f(f2bf(u)) : 0.f;
-            v[c2 * 4 + j] = u;
-            if (EPI == 0) { ssum[h][c2 * 4 + j] += u; ssq[h][c2 * 4 + j] += u * u; }
-          }
-        if (pok && cok[h]) {
-          *(uint4*)(dst + h * 32) = Chunk<bf16_t>::pack(v);
+            for (int jj = 0; jj < 2; ++jj) {
+              const f2_t a = {acc[2 * h + c2][pt][2 * jj], acc[2 * h + c2][pt][2 * jj + 1]};
+              const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(a, b2_t)) & keep;
+              pk[c2 * 2 + jj] = u;
+              const f2_t r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+              s2[h][c2 * 2 + jj] += r;
+              q2[h][c2 * 2 + jj] = __builtin_elementwise_fma(r, r, q2[h][c2 * 2 + jj]);
+            }
+          if (pok && cok[h]) *(uint4*)(dst + h * 32) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int pt = 0; pt < 8; ++pt) {
+        const int yy = cur.y0 + wrow0 + pt;
+        const bool pok = xok & (yy < p.H);
+        bf16_t* dst = p.y + (((long)bb * p.H + yy) * p.W + cur.x0 + e_lp) * p.ysw + (long)cur.g * p.Cn + cur.c0 + cl0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float u = acc[2 * h + c2][pt][j];
+              u = u * sv[h][c2 * 4 + j] + hv[h][c2 * 4 + j];
+              if (p.act) u = silu_f(u);
+              v[c2 * 4 + j] = u;
+            }
+          if (pok && cok[h]) *(uint4*)(dst + h * 32) = Chunk<bf16_t>::pack(v);
         }
       }
     }
@@ -339,11 +372,11 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          float s = wave_xor_sum16(ssum[h][i]);
-          float q2 = wave_xor_sum16(ssq[h][i]);
+          float s = wave_xor_sum16(s2[h][i >> 1][i & 1]);
+          float qq = wave_xor_sum16(q2[h][i >> 1][i & 1]);
           if (e_lp == i) {
             red[(wp * 128 + cl0 + h * 32 + i) * 2 + 0] = s;
-            red[(wp * 128 + cl0 + h * 32 + i) * 2 + 1] = q2;
+            red[(wp * 128 + cl0 + h * 32 + i) * 2 + 1] = qq;
           }
         }
       lgk0();  // not __syncthreads(): its fence would drain the DMA prefetch of the next tile

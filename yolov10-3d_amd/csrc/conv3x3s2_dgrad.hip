@@ -30,7 +30,8 @@ struct S2P {
 template <int N> __device__ __forceinline__ void s2_wvm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 typedef __attribute__((ext_vector_type(2))) unsigned s2_u32x2;
 
-// NSLAB: Cout / 64 (64-channel K slabs: 128-byte LDS rows)
+// NSLAB: ceil(Cout / 64) (64-channel K slabs: 128-byte LDS rows; the chunks past Cout - 96 output channels of the M widths - are zeros:
+// weights below, halo by out-of-range DMA lanes)
 template <int NSLAB>
 __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
   constexpr int TH = 8, HW = 17, SLOTS = 160;       // (TH + 1) * 17 = 153 halo pixels, padded to 20 DMA instructions of 8 slots
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
     const int tap = ts / NSLAB, sl = ts - tap * NSLAB;
     const int ci = ci0 + r;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (ci < p.Cin) v = *(const uint4*)(p.w + (long)ci * p.Kpad + tap * p.Cout + sl * 64 + c * 8);
+    if (ci < p.Cin && sl * 64 + c * 8 < p.Cout) v = *(const uint4*)(p.w + (long)ci * p.Kpad + tap * p.Cout + sl * 64 + c * 8);
     *(uint4*)(sW + (ts * 32 + r) * 128 + ((c ^ (r & 7)) << 4)) = v;
   }
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
     const int P = s8 * 8 + (lane >> 3);
     const int row = P / HW, col = P - row * HW;
     p_off[n] = (row * p.Wo + col) * p.dsw + sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3);
-    p_rc[n] = ((P < (TH + 1) * HW ? row : 255) << 8) | col;
+    p_rc[n] = (((P < (TH + 1) * HW) & (sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3) < p.Cout) ? row : 255) << 8) | col;
   }
   auto issue = [&](int t, int buf) {
     int b, hy0, wx0;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
 extern "C" int y3d_get_stream1x1(void);
 
 int y3d_conv3x3s2_dgrad_ok(int dtype, int B, int Ho, int Wo, int H, int W, int Cout, int Cin, long dsw, long xsw) {
-  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || (Cout != 64 && Cout != 128) || Cin % 4 != 0 || Cin < 8) return 0;
+  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || Cout < 32 || Cout > 128 || Cout % 8 != 0 || Cin % 4 != 0 || Cin < 8) return 0;
   if (Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return 0;
   if (((long)B * Ho * Wo * dsw + Cout) * 2 >= (1L << 32) - 64 || ((long)B * H * W * xsw + Cin) * 2 >= (1L << 32) - 64) return 0;
   return 1;
@@ -184,7 +185,7 @@ int y3d_conv3x3s2_dgrad_launch(const void* dy, long dsw, int B, int Ho, int Wo, 
   p.nty = cdiv(Ho, 8); p.ntx = cdiv(Wo, 16); p.ntiles = B * p.nty * p.ntx;
   p.dbytes = (unsigned)((((long)B * Ho * Wo - 1) * dsw + Cout) * 2);
   p.xbytes = (unsigned)((((long)B * H * W - 1) * xsw + Cin) * 2);
-  const int nslab = Cout / 64;
+  const int nslab = cdiv(Cout, 64);
   const size_t lds = (size_t)9 * nslab * 32 * 128 + 2 * (size_t)nslab * 160 * 128;
   const int nci = cdiv(Cin, 32);
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;

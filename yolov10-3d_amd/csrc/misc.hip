@@ -400,6 +400,26 @@ __global__ void stem_im2col_u8_kernel(const unsigned char* __restrict__ x, int h
     Y3D_LAUNCH_CHECK();                                                                       \
   } while (0)
 
+
+// diagnostic (tools/cu_contention.py): `n` workgroups that stay resident - one wave each polling `flag` between sleeps, the others
+// copying inside `buf` at a trickle - until *flag != 0 or ~50 ms have passed (every wave reaches the exit: bounded loop)
+__global__ __launch_bounds__(256) void occupy_cus_kernel(const int* __restrict__ flag, float* __restrict__ buf, long nbuf) {
+  __shared__ int stop;
+  if (threadIdx.x == 0) stop = 0;
+  __syncthreads();
+  const long chunk = nbuf / (2 * (long)gridDim.x);
+  float* src = buf + (long)blockIdx.x * 2 * chunk;
+  float* dst = src + chunk;
+  for (int it = 0; it < 50000; ++it) {  // ~1 us per round
+    if (threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) stop = 1;
+    const long o = ((long)it * 256 + threadIdx.x) % (chunk > 256 ? chunk - 256 : 1);
+    dst[o] = src[o] + 1.f;
+    __builtin_amdgcn_s_sleep(64);
+    __syncthreads();
+    if (stop) break;
+  }
+}
+
 static int chk(const char* what, int dtype, int C, const void* a, long s0, long s1, long s2) {
   int ce = dtype == Y3D_BF16 ? 8 : 4;
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "%s: bad dtype", what);
@@ -447,6 +467,13 @@ int y3d_upsample2x_bwd(int dtype, const void* dy, int64_t dsb, int64_t dsh, int6
   long total = (long)B * H * W * (C / (dtype == Y3D_BF16 ? 8 : 4));
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)dsb, (long)dsh, (long)dsw, (bf16_t*)dx, (long)xsw, B, H, W, C);
   else hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)dsb, (long)dsh, (long)dsw, (float*)dx, (long)xsw, B, H, W, C);
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+int y3d_occupy_cus(int n, const int* flag, float* buf, int64_t nbuf, void* stream) {
+  Y3D_CHECK(n >= 1 && n <= 256 && flag && buf && nbuf >= 1024L * n, "occupy_cus: 1..256 workgroups, a flag and a buffer of >= 1024 floats per workgroup");
+  hipLaunchKernelGGL(occupy_cus_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, flag, buf, (long)nbuf);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

@@ -1,4 +1,5 @@
-// Weight gradient of the NARROW 3x3 stride-1 "same" convs (32 or 64 input channels, 32 / 48 / 64 output channels; bf16) - the partner of
+// Weight gradient of the NARROW 3x3 stride-1 "same" convs (32 or 64 input channels - or 40 / 48 / 56 in zero-padded 64-channel rows: the M
+// widths - 32 / 48 / 64 output channels; bf16) - the partner of
 // conv3x3_small.hip:
 //
 //     slab[split][co][tap * Cin + ci] = sum over the split's pixels p of dy[p][co] * x[p + tap][ci]
@@ -20,7 +21,7 @@ struct WsP {
   const bf16_t* dy;
   float* slab;  // [gridDim.x][Cout][9 * Cin]
   int xsb, xsh, xsw, dsw;
-  int B, H, W, Cout;
+  int B, H, W, Cout, Cin;  // Cin <= CB / 2 real input channels (the rest of an LDS row stays zero)
   int nty, ntx, ntiles;
   unsigned xbytes, dbytes;
 };
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(WsP p) {
     } else {
       const int q = (gi - ID) * 64 + lane, P = q / CPX, col = q - P * CPX;
       const int hr = P / HW, hc = P - hr * HW;
-      const bool ok = (gi < ID + IX) & (P < NPIX) & (col < CB / 16);
+      const bool ok = (gi < ID + IX) & (P < NPIX) & (col < CB / 16) & (col * 8 < p.Cin);
       p_off[n] = (hr - 1) * p.xsh + (hc - 1) * p.xsw + col * 8;
       p_rc[n] = ((ok ? hr : 255) << 8) | hc;  // halo coordinates: image row y0 - 1 + hr, column x0 - 1 + hc
     }
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(WsP p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // D[row = 4g + r -> output channel of tile a][column li -> input channel of this wave's tile]
-  float* slab = p.slab + (long)wk * p.Cout * (9 * CIN);
+  const int cin = p.Cin;
+  float* slab = p.slab + (long)wk * p.Cout * (9 * cin);
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(WsP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = (wco * CT + a) * 16 + 4 * g + r;
-        if (co < p.Cout) slab[(long)co * (9 * CIN) + t * CIN + wci * 16 + li] = acc[t][a][r];
+        if (co < p.Cout && wci * 16 + li < cin) slab[(long)co * (9 * cin) + t * cin + wci * 16 + li] = acc[t][a][r];
       }
 }
 
@@ -223,7 +225,7 @@ void ws_launch(const WsP& p, int grid, hipStream_t st) {
 extern "C" int y3d_get_stream1x1(void);
 
 int y3d_wgrad3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout) {
-  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || (Cin != 32 && Cin != 64) || Cout % 16 != 0 || Cout < 16 || Cout > 64) return 0;
+  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || (Cin != 32 && (Cin <= 32 || Cin > 64 || Cin % 8 != 0)) || Cout % 16 != 0 || Cout < 16 || Cout > 64) return 0;
   if (Cin == 32 && (Cout / 16) % 2 != 0) return 0;  // two waves share the output-channel tiles
   if (H < 4 || W < 8) return 0;
   return 1;
@@ -248,12 +250,12 @@ int y3d_wgrad3x3_small_launch(const void* x, long xsb, long xsh, long xsw, const
   WsP p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.slab = slab;
   p.xsb = (int)xsb; p.xsh = (int)xsh; p.xsw = (int)xsw; p.dsw = (int)dsw;
-  p.B = B; p.H = H; p.W = W; p.Cout = Cout;
+  p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.Cin = Cin;
   p.nty = cdiv(H, 8); p.ntx = cdiv(W, 16); p.ntiles = B * p.nty * p.ntx;
   p.xbytes = (unsigned)xext; p.dbytes = (unsigned)dext;
   hipStream_t st = (hipStream_t)stream;
   const int nct = Cout / 16;
-  if (Cin == 64) {
+  if (Cin > 32) {
     switch (nct) {
       case 1: ws_launch<128, 1>(p, nsplit, st); break;
       case 2: ws_launch<128, 2>(p, nsplit, st); break;
