@@ -161,6 +161,8 @@ def main(argv=None):
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--phases", action="store_true", help="per-phase device times (backward / all-reduce / optimizer) in the JSON line (default for N > 1)")
     ap.add_argument("--no-phases", action="store_true", help="N > 1: no per-phase events")
+    ap.add_argument("--train-graph", action="store_true",
+                    help="also time the training step replayed from ONE hipGraph (graph.GraphedTrainStep; 1 GPU): `train_images_per_sec_graph`")
     ap.add_argument("--infer-mode", default="graph", choices=["graph", "eager"],
                     help="inference leg: replay the eval forward + postprocess from one captured hipGraph per batch (default), or launch eagerly")
     args = ap.parse_args(argv)
@@ -284,6 +286,33 @@ def main(argv=None):
     assert torch.isfinite(items).all(), f"non-finite loss items {items}"
     train_ips = world * B * args.steps / dt_s
 
+    train_graph_ips = None
+    if args.train_graph and world == 1 and reducer is None:
+        # the same step - forward, loss, backward, clip, SGD - replayed from one captured hipGraph, EMA eagerly behind it; the batches
+        # rotate through the graph's static buffers
+        try:
+            from yolov10_3d_amd.graph import GraphedTrainStep
+            opt.zero_grad(set_to_none=True)
+            gstep = GraphedTrainStep(model, opt, batches[0], max_norm=10.0)
+            for j in range(2):
+                gstep(batches[j % NBATCH])
+                if ema is not None:
+                    ema.update(model, guard=opt.last_norm)
+            sync()
+            tg = time.perf_counter()
+            for j in range(args.steps):
+                gl, gitems = gstep(batches[j % NBATCH])
+                if ema is not None:
+                    ema.update(model, guard=opt.last_norm)
+            sync()
+            tg = time.perf_counter() - tg
+            assert torch.isfinite(gitems).all(), f"non-finite loss items from the graphed step {gitems}"
+            train_graph_ips = B * args.steps / tg
+            log(f"graph-replayed train step: {1e3 * tg / args.steps:.2f} ms/step ({train_graph_ips:.1f} images/s)")
+            opt.zero_grad(set_to_none=True)
+        except Exception as e:
+            log(f"hipGraph capture of the training step failed ({type(e).__name__}: {e})")
+
     # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190: "Speed: ... ms per image").  The forward
     # is ~200 launches of 3-150 us: enqueued eagerly the host is the bound (tools/eval_audit.py), so the timed loop replays ONE captured
     # hipGraph per batch (yolov10-3d_amd/graph.py; --infer-mode eager keeps the launch-by-launch loop); the eager rate is reported next to it
@@ -381,11 +410,12 @@ def main(argv=None):
         out = {
             "metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype if args.weights == "full" else "fp8w", "data": "synthetic",
-            "config": {"workload": f"{args.model}{' (3D head)' if is3d else ' (2D head)'}, {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' on fp8 e4m3 conv weights'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model}{' (3D head)' if is3d else ' (2D head)'}, {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' MFMA on fp8 e4m3-VALUED conv weights (weight-format emulation: no fp8 MFMA instruction runs, no speed claim)'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": args.backend if dist.is_initialized() else None,
             "steps_skipped_nonfinite": int(opt.last_norm[4]) if opt.last_norm is not None else None,
+            "train_images_per_sec_graph": round(train_graph_ips, 2) if train_graph_ips else None,
             "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None, "infer_mode": infer_mode if infer_ips else None,
             "infer_images_per_sec_eager": round(infer_eager_ips, 2) if infer_eager_ips else None, "roofline_infer": roof_infer,
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],

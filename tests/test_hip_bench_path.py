@@ -988,3 +988,50 @@ def test_pad_targets_overflow_is_reported():
     gt, n_used = PL.pad_targets(rows[60:], 2, 5, (64.0, 64.0))  # 10 + 3 boxes: fine
     PL.check_target_overflow(wait=True)
     assert int(n_used) == 10
+
+
+@pytest.mark.parametrize("G,Cg,Cn,hw,B", [(14, 64, 64, (40, 40), 3), (2, 96, 40, (17, 23), 2), (16, 64, 24, (24, 24), 2)], ids=["m_head_14x64", "2x96to40", "16x64to24"])
+def test_grouped_1x1_streaming_kernel_exact(G, Cg, Cn, hw, B):
+    """grouped 1x1 convs (the second head layer of the M widths: 14 groups of 64 -> 64, k = 1) on the streaming kernel's group
+    dimension (round 3): y, the BatchNorm partial sums and dx against fp32 conv2d / conv_transpose on small-integer operands (exact),
+    and bit-identical to the generic kernel; the weight gradient (generic path) alongside"""
+    H, W = hw
+    gen = torch.Generator().manual_seed(G * 1000 + Cg + Cn)
+    xf, wf, dyf = _sparse_int((B, G * Cg, H, W), gen, 0.25), _sparse_int((G * Cn, Cg, 1, 1), gen, 0.25), _sparse_int((B, G * Cn, H, W), gen, 0.25)
+    L, st, dt, bf = y3d.lib(), ops.stream(), BF16, torch.bfloat16
+    y3d.set_compute_dtype(bf)
+    outs = []
+    for flag in (1, 0):
+        old = L.set_stream1x1(flag)
+        try:
+            xin = ops.nhwc_empty(B, G * Cg, H, W, bf, DEV)
+            xin.copy_(xf.to(DEV))
+            dyd = ops.nhwc_empty(B, G * Cn, H, W, bf, DEV)
+            dyd.copy_(dyf.to(DEV))
+            wd = wf.to(DEV).contiguous()
+            sb, sh, sw = ops.s3(xin)
+            wp = torch.empty(G * Cn * Cg, dtype=bf, device=DEV)
+            L.pack_weight_fwd(dt, wd.data_ptr(), wp.data_ptr(), G * Cn, Cg, Cg, 1, 1, st)
+            nblk = L.conv2d_stat_rows(dt, B, H, W, G * Cg, G * Cn, G, 1, 1, 1, 0)
+            part = torch.full((nblk, G * Cn, 2), float("nan"), dtype=torch.float32, device=DEV)
+            y = ops.nhwc_empty(B, G * Cn, H, W, bf, DEV)
+            L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, G * Cg, wp.data_ptr(), None, y.data_ptr(), G * Cn, H, W, G * Cn, G, 1, 1, 1, 0, part.data_ptr(), st)
+            kp = L.conv_kpad(dt, Cn)
+            wpd = torch.empty(G * Cg * kp, dtype=bf, device=DEV)
+            L.pack_weight_dgrad(dt, wd.data_ptr(), wpd.data_ptr(), G * Cn, Cg, G, 1, 1, st)
+            dx = ops.nhwc_empty(B, G * Cg, H, W, bf, DEV)
+            dsb, dsh, dsw = ops.s3(dyd)
+            L.conv2d_bwd_data(dt, dyd.data_ptr(), dsb, dsh, dsw, B, H, W, G * Cn, wpd.data_ptr(), dx.data_ptr(), G * Cg, H, W, G * Cg, G, 1, 1, 1, 0, st)
+            torch.cuda.synchronize()
+            outs.append((y.float().cpu(), part.double().sum(0).cpu(), dx.float().cpu(), nblk))
+        finally:
+            L.set_stream1x1(old)
+    ref_y = F.conv2d(xf, wf, groups=G)
+    ref_dx = torch.nn.grad.conv2d_input(xf.shape, wf, dyf, groups=G)
+    ref_st = torch.stack((ref_y.double().sum((0, 2, 3)), (ref_y.double() ** 2).sum((0, 2, 3))), 1)
+    if Cg >= 32 and Cn % 4 == 0 and B * H * W >= 128:
+        assert outs[0][3] != outs[1][3] or G == 1, "the streaming kernel was expected to take this shape (its partial rows are its workers)"
+    for (yy, stt, dxx, _), which in zip(outs, ("streaming", "generic")):
+        assert torch.equal(yy, ref_y), f"y ({which})"
+        assert torch.equal(stt, ref_st), f"BatchNorm partial sums ({which})"
+        assert torch.equal(dxx, ref_dx), f"dx ({which})"

@@ -1011,3 +1011,47 @@ def test_graphed_eval_forward_replays_the_eager_forward():
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
     assert not torch.equal(ref[0], eager[1][0]), "the training step did not change the eval output: the test would not see a stale capture"
+
+
+def test_graphed_train_step_matches_eager_steps():
+    """graph.GraphedTrainStep: three training steps replayed from one hipGraph leave the model where three eager steps leave it (same
+    kernels on the same data in the same order: bit for bit) - parameters, BatchNorm running statistics, momentum buffers and the
+    loss items of every step; batches with different box counts go through the padded static label buffers"""
+    from bench import synth_batch
+    from yolov10_3d_amd.graph import GraphedTrainStep
+    from yolov10_3d_amd.optim import build_optimizer
+    y3d.set_compute_dtype(torch.bfloat16)
+    batches = [synth_batch(2, 256, 256, 20 + j, DEV) for j in range(3)]
+    assert len({b["batch_idx"].shape[0] for b in batches}) > 1, "the batches should differ in their box counts"
+    res = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(3)
+        model = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml").to(DEV).train()
+        opt = build_optimizer(model, lr=0.01)
+        model.model[-1].restack()
+        items = []
+        if mode == "eager":
+            for b in batches:
+                loss, it = model(b)
+                loss.backward()
+                opt.step(max_norm=10.0)
+                opt.zero_grad()
+                items.append(it.float().cpu())
+        else:
+            state0 = {k: v.clone() for k, v in model.state_dict().items()}
+            step = GraphedTrainStep(model, opt, batches[0])
+            # the warm-up step moved the model: start over from the initial state (and zero momentum) so that both modes run the same three steps
+            model.load_state_dict(state0)
+            opt._state["flat"].zero_()
+            for m in step.convs:
+                m._nbt_pending = 0
+            for b in batches:
+                loss, it = step(b)
+                items.append(it.float().cpu().clone())
+        torch.cuda.synchronize()
+        res[mode] = (items, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}, opt._state["flat"].cpu().clone())
+    for a, b in zip(res["eager"][0], res["graph"][0]):
+        assert torch.equal(a, b), (a, b)
+    for k, v in res["eager"][1].items():
+        assert torch.equal(v, res["graph"][1][k]), f"state {k} differs after three steps"
+    assert torch.equal(res["eager"][2], res["graph"][2]), "momentum buffers differ"

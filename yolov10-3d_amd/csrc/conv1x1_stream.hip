@@ -36,6 +36,7 @@ struct PwP {
   int xsw;      // pixel stride of x in elements
   int M, K, N, Kpad;
   int nkc, nmt, nnt, act;
+  int G, PC;    // groups (blockIdx.y; K, N, Kpad are per group, the operands of group g start g * K / g * N channels further), channels of a partial row
   unsigned xbytes, ybytes, pbytes, wbytes;
 };
 
@@ -60,6 +61,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned pw_u32x2;
 // chunk travels in the ring next to the pixel chunk (a stage is 16 KB of pixels + BN x 128 B of weights, the weights out of L2).
 template <int BN, int WP, int WC, int NS, bool AFF, bool WRES>
 __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
+  {  // grouped 1x1 (the M head's second layer: 14 groups of 64 -> 64): blockIdx.y picks the group, everything below sees ITS operands
+    const int g = blockIdx.y;
+    p.x += (long)g * p.K;
+    p.w += (long)g * p.N * p.Kpad;
+    p.y += (long)g * p.N;
+    if (p.bias) p.bias += g * p.N;
+    if (p.scale) { p.scale += g * p.N; p.shift += g * p.N; }
+    if (p.part) p.part += (long)g * p.N * 2;
+  }
   constexpr int BM = 128;
   constexpr int TP = BM / WP / 16, TC = BN / WC / 16;
   static_assert(WP * WC == 8 && TP >= 1 && TC >= 1, "8 waves");
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
   const int mine = wk < p.nmt ? (p.nmt - wk + nwk - 1) / nwk : 0;
   const int S = mine * p.nkc;
   if (S == 0) {  // a worker without tiles (the grid is a multiple of 8): its row of BatchNorm partials is zeros
-    if (p.part && tid < BN && n0 + tid < p.N) *(float2*)(p.part + ((long)wk * p.N + n0 + tid) * 2) = make_float2(0.f, 0.f);
+    if (p.part && tid < BN && n0 + tid < p.N) *(float2*)(p.part + ((long)wk * p.PC + n0 + tid) * 2) = make_float2(0.f, 0.f);
     return;
   }
 
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(PwP p) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WP; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-      float* dst = p.part + ((long)wk * p.N + n0 + tid) * 2;
+      float* dst = p.part + ((long)wk * p.PC + n0 + tid) * 2;
       dst[0] = s;
       dst[1] = q;
     }
@@ -252,7 +262,7 @@ struct PwPlan {
 // Resident weights: BN = the smallest tile covering N whose weights leave room for a 3-stage ring; otherwise the largest that fits.
 // More than two channel tiles would stream the pixels again and again (and a 64-channel tile with a six-stage ring measured 20-60 %
 // slower than the generic kernel on the 40x40 / 20x20 layers): those layers stream their weight chunk through the ring instead.
-bool pw_plan(int M, int K, int N, PwPlan* pl) {
+bool pw_plan(int M, int K, int N, PwPlan* pl, int G = 1) {
   const int nkc = cdiv(K, 64);
   const size_t cap = 160 * 1024;
   const int nmt = cdiv(M, 128);
@@ -286,7 +296,7 @@ bool pw_plan(int M, int K, int N, PwPlan* pl) {
   }
   pl->nnt = cdiv(N, pl->bn);
   const int per_cu = pl->lds <= 80 * 1024 ? 2 : 1;
-  int wpx = (32 * per_cu) / pl->nnt;  // workers per XCD
+  int wpx = (32 * per_cu) / (pl->nnt * G);  // workers per XCD (and group)
   if (wpx < 1) wpx = 1;
   if (wpx > cdiv(nmt, 8)) wpx = cdiv(nmt, 8);
   pl->grid = 8 * wpx * pl->nnt;
@@ -300,7 +310,7 @@ void pw_launch_1(const PwP& p, const PwPlan& pl, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<BN, WP, WC, NS, AFF, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv1x1_stream_kernel<BN, WP, WC, NS, AFF, WRES>), dim3(pl.grid), dim3(512), pl.lds, st, p);
+  hipLaunchKernelGGL((conv1x1_stream_kernel<BN, WP, WC, NS, AFF, WRES>), dim3(pl.grid, p.G), dim3(512), pl.lds, st, p);
 }
 
 template <int BN, int WP, int WC>
@@ -324,33 +334,33 @@ extern "C" int y3d_set_stream1x1(int enable) {
 
 // Does the streaming kernel take this GEMM?  (bf16, K a multiple of 32, dense pixel rows, 32-bit byte offsets, at most `max_nnt`
 // channel tiles: every extra channel tile streams the pixel operand again)
-int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw) {
-  if (!g_stream1x1 || dtype != Y3D_BF16 || K % 8 != 0 || K < 32 || N < 8 || N % 4 != 0 || M < 128) return 0;
-  if ((M * xsw + K) * 2 >= (1L << 32) - 64 || M * N * 2 >= (1L << 31)) return 0;
+int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw, int G) {
+  if (!g_stream1x1 || dtype != Y3D_BF16 || K % 8 != 0 || K < 32 || N < 8 || N % 4 != 0 || M < 128 || G < 1 || G > 64) return 0;
+  if ((M * xsw + (long)G * K) * 2 >= (1L << 32) - 64 || M * N * G * 2 >= (1L << 31)) return 0;
   PwPlan pl;
-  if (!pw_plan((int)M, K, N, &pl)) return 0;
+  if (!pw_plan((int)M, K, N, &pl, G)) return 0;
   return 1;
 }
 
 // rows of BatchNorm partials the kernel writes for this GEMM (= its worker count)
-int y3d_conv1x1_stream_rows(long M, int K, int N) {
+int y3d_conv1x1_stream_rows(long M, int K, int N, int G) {
   PwPlan pl;
-  if (!pw_plan((int)M, K, N, &pl)) return 0;
+  if (!pw_plan((int)M, K, N, &pl, G)) return 0;
   return pl.grid / pl.nnt;
 }
 
 int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, const float* bias, const float* scale, const float* shift, int act,
-                              void* y, long ysw, float* part, long M, int K, int N, void* stream) {
+                              void* y, long ysw, float* part, long M, int K, int N, int G, void* stream) {
   PwPlan pl;
-  Y3D_CHECK(pw_plan((int)M, K, N, &pl), "conv1x1_stream: no tile plan for K=%d N=%d", K, N);
+  Y3D_CHECK(pw_plan((int)M, K, N, &pl, G), "conv1x1_stream: no tile plan for K=%d N=%d", K, N);
   Y3D_CHECK(((uintptr_t)x & 15) == 0 && xsw % 8 == 0 && ((uintptr_t)w & 15) == 0 && Kpad % 8 == 0 && ((uintptr_t)y & 7) == 0 && ysw % 4 == 0,
             "conv1x1_stream: operand alignment");
   PwP p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.scale = scale; p.shift = shift; p.y = (bf16_t*)y; p.part = part;
   p.ysw = ysw; p.xsw = (int)xsw; p.M = (int)M; p.K = K; p.N = N; p.Kpad = Kpad;
-  p.nkc = cdiv(K, 64); p.nmt = cdiv(M, 128); p.nnt = pl.nnt; p.act = act;
+  p.nkc = cdiv(K, 64); p.nmt = cdiv(M, 128); p.nnt = pl.nnt; p.act = act; p.G = G; p.PC = G * N;
   p.xbytes = (unsigned)(((M - 1) * xsw + K) * 2);
-  Y3D_CHECK(((M - 1) * ysw + N) * 2 < (1L << 32) - 64 && M * ysw < (1L << 31), "conv1x1_stream: output tensor beyond 32-bit byte offsets");
+  Y3D_CHECK(((M - 1) * ysw + (long)G * N) * 2 < (1L << 32) - 64 && M * ysw < (1L << 31), "conv1x1_stream: output tensor beyond 32-bit byte offsets");
   p.ybytes = (unsigned)(((M - 1) * ysw + N) * 2);
   p.pbytes = part ? (unsigned)((long)p.nmt * N * 8) : 0u;
   hipStream_t st = (hipStream_t)stream;

@@ -758,9 +758,9 @@ int y3d_conv3x3_wgrad_tile_launch(int th, const void* x, long xsb, long xsh, lon
                                   int Cn, int G, float* slab, int nsplit, void* stream);
 
 // conv1x1_stream.hip
-int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw);
+int y3d_conv1x1_stream_ok(int dtype, long M, int K, int N, long xsw, int G = 1);
 int y3d_conv1x1_stream_launch(const void* x, long xsw, const void* w, int Kpad, const float* bias, const float* scale, const float* shift, int act,
-                              void* y, long ysw, float* part, long M, int K, int N, void* stream);
+                              void* y, long ysw, float* part, long M, int K, int N, int G, void* stream);
 // wgrad1x1_stream.hip
 int y3d_wgrad1x1_stream_ok(int dtype, long M, int Cg, int Cn, long xsw, long dsw);
 int y3d_wgrad1x1_stream_launch(const void* x, long xsw, const void* dy, long dsw, long M, int Cg, int Cn, float* slab, int nsplit, int chunk_px,
@@ -774,7 +774,7 @@ int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int 
 int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
                              long ysw, float* part, int rows, int flip, void* stream);
 int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout);
-int y3d_conv1x1_stream_rows(long M, int K, int N);
+int y3d_conv1x1_stream_rows(long M, int K, int N, int G = 1);
 extern "C" int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
 // wgrad3x3_small.hip
 int y3d_wgrad3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout);
@@ -821,8 +821,8 @@ int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int
 
 int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
   // the persistent kernels write one row per workgroup (a few hundred rows whatever the map size)
-  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && y3d_conv1x1_stream_ok(dtype, (long)B * H * W, Cin, Cout, Cin))
-    return y3d_conv1x1_stream_rows((long)B * H * W, Cin, Cout);
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups >= 1 && y3d_conv1x1_stream_ok(dtype, (long)B * H * W, Cin / groups, Cout / groups, Cin, groups))
+    return y3d_conv1x1_stream_rows((long)B * H * W, Cin / groups, Cout / groups, groups);
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, 1))
     return y3d_conv3x3_small_rows(B, H, W, Cin, Cout);
   int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, B, H, W, Cin / groups, Cout / groups, groups, kh, kw, stride, pad) : 0;
@@ -892,12 +892,12 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
   p.Cg = Cin / groups; p.Cn = Cout / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = p.Ktot; p.M = B * Ho * Wo;
-  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, H, W, xsb, xsh, xsw) &&
-      y3d_conv1x1_stream_ok(dtype, p.M, Cin, Cout, xsw))
-    return y3d_conv1x1_stream_launch(x, xsw, w_packed, p.Kpad, bias, scale, shift, act, y, ysw, stat_partials, p.M, Cin, Cout, stream);
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && dense_pixels(B, H, W, xsb, xsh, xsw) &&
+      y3d_conv1x1_stream_ok(dtype, p.M, p.Cg, p.Cn, xsw, groups))
+    return y3d_conv1x1_stream_launch(x, xsw, w_packed, p.Kpad, bias, scale, shift, act, y, ysw, stat_partials, p.M, p.Cg, p.Cn, groups, stream);
   // y3d_conv2d_stat_rows sized the caller's partial buffer for the streaming kernel: an operand it cannot take (a view that is not
   // pixel-dense, or beyond 32-bit byte offsets) must not fall through to the generic kernel's one-row-per-tile layout
-  Y3D_CHECK(!(stat_partials && kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && y3d_conv1x1_stream_ok(dtype, p.M, Cin, Cout, Cin)),
+  Y3D_CHECK(!(stat_partials && kh == 1 && kw == 1 && stride == 1 && pad == 0 && y3d_conv1x1_stream_ok(dtype, p.M, p.Cg, p.Cn, Cin, groups)),
             "conv2d_fwd: 1x1 input view must be pixel-dense and below 4 GB for the BatchNorm partial layout of this shape");
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && !bias && !scale) {
     const int rows = stat_partials ? y3d_conv2d_stat_rows(dtype, B, H, W, Cin, Cout, groups, kh, kw, stride, pad) : 1;
@@ -945,9 +945,9 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
   p.Cg = Cout / groups; p.Cn = Cin / groups; p.G = groups;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.Ktot = kh * kw * p.Cg; p.Kpad = y3d_conv_kpad(dtype, p.Ktot); p.M = B * H * W;
-  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
-      y3d_conv1x1_stream_ok(dtype, p.M, Cout, Cin, dsw))
-    return y3d_conv1x1_stream_launch(dy, dsw, w_packed_dgrad, p.Kpad, nullptr, nullptr, nullptr, 0, dx, xsw, nullptr, p.M, Cout, Cin, stream);
+  if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
+      y3d_conv1x1_stream_ok(dtype, p.M, p.Cg, p.Cn, dsw, groups))
+    return y3d_conv1x1_stream_launch(dy, dsw, w_packed_dgrad, p.Kpad, nullptr, nullptr, nullptr, 0, dx, xsw, nullptr, p.M, p.Cg, p.Cn, groups, stream);
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && Ho == H && Wo == W && y3d_conv3x3_small_ok(dtype, B, H, W, Cout, Cin, 1))
     return y3d_conv3x3_small_launch(dy, dsb, dsh, dsw, B, H, W, Cout, Cin, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, 1, stream);
   if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&

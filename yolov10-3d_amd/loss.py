@@ -55,13 +55,15 @@ def pad_targets(rows, B, width, scale_xy, cap=TARGET_CAP):
     (ADVICE round 2).  -> (gt (B, cap, width) fp32, n_used (1,) int32: min(largest count, cap))"""
     if not rows.is_cuda:
         raise Y3DError("pad_targets runs on the HIP kernel of tal_loss3d.hip: the batch must live on a HIP device (no CPU fallback)")
-    check_target_overflow()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        check_target_overflow()
     rows = rows.float().contiguous()
     out = torch.empty(B, cap, width, dtype=torch.float32, device=rows.device)
     n_used = torch.empty(2, dtype=torch.int32, device=rows.device)  # [min(count, cap), true count]
     lib().pad_targets(rows.data_ptr(), rows.shape[0], width, B, cap, float(scale_xy[0]), float(scale_xy[1]), out.data_ptr(), n_used.data_ptr(),
                       ops.stream())
-    if not torch.cuda.is_current_stream_capturing():
+    if not capturing:  # (inside a hipGraph capture the read-back is left out: graph.GraphedTrainStep bounds the rows by its label capacity)
         host = torch.empty(1, dtype=torch.int32).pin_memory()
         host.copy_(n_used[1:2], non_blocking=True)
         ev = torch.cuda.Event()

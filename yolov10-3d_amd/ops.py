@@ -95,10 +95,38 @@ def concat_buffer(x, C, H=None, W=None):
 _CONCAT_BASE = {}
 
 
+# gradient placement (the mirror image of `place` for the backward pass): SplitChannelsFn hands channel slices of one map to several
+# consumers; a consumer whose backward ends in a data-gradient kernel writes that gradient straight into ITS slice of one shared
+# gradient buffer, and SplitChannelsFn.backward returns the buffer instead of concatenating the pieces (0.8 ms per step on the M head).
+# key: (address, channels) of a slice as the consumer receives it -> (holder dict, channel offset)
+_GRAD_SLOT = {}
+
+
+def grad_slot(x):
+    """the slice of the shared gradient buffer that belongs to input `x` of a consumer (a view made by SplitChannelsFn), or None"""
+    ent = _GRAD_SLOT.get((x.data_ptr(), x.shape[1]))
+    if ent is None:
+        return None
+    holder, off = ent
+    if holder["shape"] != (x.shape[0], x.shape[2], x.shape[3]) or holder["dtype"] != x.dtype:
+        return None
+    return holder, off, x.shape[1]
+
+
+def grad_slot_tensor(slot):
+    """materialise (once) the shared buffer of a slot and return this consumer's slice of it"""
+    holder, off, w = slot
+    if holder["buf"] is None:
+        B, H, W = holder["shape"]
+        holder["buf"] = nhwc_empty(B, holder["C"], H, W, holder["dtype"], holder["device"])
+    return holder["buf"][:, off:off + w]
+
+
 def reset_placement():
     global _PLACE
     _PLACE = None
     _CONCAT_BASE.clear()
+    _GRAD_SLOT.clear()
 
 
 def out_tensor(B, C, H, W, dtype, device):
@@ -518,7 +546,7 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
 
 
-def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
+def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None, dx_out=None):
     """-> dx, dW (fp32 OIHW), dgamma, dbeta, dres.  dx_range=(lo, hi): only output channels lo..hi feed dx
     (the one-to-one head sees a detached input, reference head.py:820)."""
     L = lib()
@@ -528,7 +556,7 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
     if not training:
         raise Y3DError("backward through an eval-mode (running-statistics) Conv is not supported")
     if pre is not None:  # (dy, dgb): the BatchNorm part was done by the caller (FusedConvBNProjFn)
-        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range)
+        return _conv_backward(cfg, saved, pre[0], pre[1], None, need_dx, dx_range, dx_out)
     dt = code(dtype)
     st = stream()
     dev = dz.device
@@ -552,10 +580,10 @@ def _cba_backward(cfg, saved, dz, need_dx, need_dres, dx_range=None, pre=None):
                        dy.data_ptr(), Cout, dres.data_ptr() if dres is not None else None, Cout, M, Cout, st)
     if res_mode == 1:
         dres = dz
-    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range)
+    return _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, dx_out)
 
 
-def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
+def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range, dx_out=None):
     """data and weight gradients of the conv given dy (gradient wrt its pre-BatchNorm output); cfg[17] = version token of the weights
     as the forward packed them"""
     L = lib()
@@ -593,10 +621,10 @@ def _conv_backward(cfg, saved, dy, dgb, dres, need_dx, dx_range):
                 L.pack_weight_dgrad(dt, src, wpd.data_ptr(), co, Cin // g, g, k, k, st)
             else:
                 wpd = PACK_DGRAD.lookup(w32, src, (g, co // g, Cin // g, k * k, kp, dt), dtype, wver)
-            dx = nhwc_empty(B, Cin, H, W, dtype, dev)
+            dx = dx_out if dx_out is not None else nhwc_empty(B, Cin, H, W, dtype, dev)  # dx_out: a slice of a shared gradient buffer (grad_slot)
             dsb, dsh, dsw = s3(dy)
             _timed(("conv_dgrad", dt, B, H, W, Cin, co, k, s, g),
-                   lambda: L.conv2d_bwd_data(dt, dy.data_ptr() + lo * esz, dsb, dsh, dsw, B, Ho, Wo, co, wpd.data_ptr(), dx.data_ptr(), Cin, H, W,
+                   lambda: L.conv2d_bwd_data(dt, dy.data_ptr() + lo * esz, dsb, dsh, dsw, B, Ho, Wo, co, wpd.data_ptr(), dx.data_ptr(), dx.stride(3), H, W,
                                              Cin, g, k, k, s, p, st))
         ns = L.conv2d_wgrad_plan(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)
         slab = _f32(ns * Cout * k * k * (Cin_k // g), dev)
@@ -705,13 +733,15 @@ class FusedConvBNActFn(torch.autograd.Function):
             for c in stack.convs:
                 c._nbt_pending += 1
         ctx.cfg, ctx.couts, ctx.dx_range = cfg, stack.couts, dx_range
+        ctx.gslot = grad_slot(x) if (m.training and torch.is_tensor(x) and x.is_cuda) else None
         if saved is not None:
             ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range)
+        dx_out = grad_slot_tensor(ctx.gslot) if (ctx.gslot is not None and ctx.needs_input_grad[0]) else None
+        dx, dW, dg, db, _ = _cba_backward(ctx.cfg, ctx.saved_tensors, dz, ctx.needs_input_grad[0], False, ctx.dx_range, dx_out=dx_out)
         dWs, dgs, dbs, off = [], [], [], 0
         for co in ctx.couts:
             dWs.append(dW[off:off + co])
@@ -727,7 +757,9 @@ class FusedConvBNActFn(torch.autograd.Function):
 class SplitChannelsFn(torch.autograd.Function):
     """x[:, o_j : o_j + m_j] for every j as strided views (no copy); the backward writes the consumers' gradients side by side into
     ONE tensor.  Plain slicing makes autograd zero-fill a full-size tensor per slice and add them up pairwise: with the 16 branches
-    of a non-uniform head (M-3D: 128-channel cls next to 64-channel regression branches) that was 15 full-map adds per level."""
+    of a non-uniform head (M-3D: 128-channel cls next to 64-channel regression branches) that was 15 full-map adds per level.
+    Round 3: consumers that end their backward in a data-gradient kernel (FusedConvBNActFn / FusedConvBNProjFn) write it straight
+    into their slice of one shared buffer (`grad_slot`), so a dense split returns that buffer without the concatenation either."""
 
     @staticmethod
     def forward(ctx, x, offs, widths):
@@ -735,12 +767,29 @@ class SplitChannelsFn(torch.autograd.Function):
         covered = sorted(zip(offs, widths))
         ctx.dense = covered[0][0] == 0 and all(a + w == b for (a, w), (b, _) in zip(covered, covered[1:])) and covered[-1][0] + covered[-1][1] == x.shape[1]
         ctx.order = [j for _, j in sorted((o, j) for j, o in enumerate(offs))]
-        return tuple(x[:, o:o + w] for o, w in zip(offs, widths))
+        outs = tuple(x[:, o:o + w] for o, w in zip(offs, widths))
+        ctx.holder = None
+        if ctx.dense and x.is_cuda and len(set(offs)) == len(offs) and all(o % ce(x.dtype) == 0 and w % ce(x.dtype) == 0 for o, w in zip(offs, widths)):
+            ctx.holder = {"buf": None, "C": x.shape[1], "shape": (x.shape[0], x.shape[2], x.shape[3]), "dtype": x.dtype, "device": x.device}
+            ctx.keys = []
+            for v, o in zip(outs, offs):
+                k = (v.data_ptr(), v.shape[1])
+                _GRAD_SLOT[k] = (ctx.holder, o)
+                ctx.keys.append(k)
+        return outs
 
     @staticmethod
     def backward(ctx, *grads):
         ref = next(g for g in grads if g is not None)
         B, _, H, W = ref.shape
+        if ctx.holder is not None:
+            for k in ctx.keys:
+                _GRAD_SLOT.pop(k, None)
+            buf = ctx.holder["buf"]
+            esz = ref.element_size()
+            if buf is not None and all(g is not None and g.dtype == buf.dtype and g.data_ptr() == buf.data_ptr() + o * esz and g.shape[1] == w
+                                       and g.stride() == buf[:, o:o + w].stride() for g, o, w in zip(grads, ctx.offs, ctx.widths)):
+                return buf, None, None  # every consumer wrote its slice in place
         if ctx.dense and all(g is not None for g in grads):
             parts = [to_nhwc(grads[j], ref.dtype, dense=True).permute(0, 2, 3, 1) for j in ctx.order]  # physical (B, H, W, c_j)
             return torch.cat(parts, 3).permute(0, 3, 1, 2), None, None
@@ -995,6 +1044,7 @@ class FusedConvBNProjFn(torch.autograd.Function):
         m = stack.convs[0]
         npar = len(params) - 2 * n
         ws, bs = params[npar:npar + n], params[npar + n:]
+        ctx.gslot = grad_slot(x) if (m.training and x.is_cuda) else None
         y, cfg, saved = _cba_forward(x, w, gm, bt, rm, rv, m.k, m.s, m.p, groups, m.has_act, None, 0, m.training, m.eps, m.momentum, bn_apply=False,
                                      ver=stack.ver)
         if m.training:
@@ -1046,6 +1096,7 @@ class FusedConvBNProjFn(torch.autograd.Function):
         dws = [torch.empty_like(t) for t in ws]
         dbs = [_f32(co, dev) for co in couts]
         mfma = dtype == torch.bfloat16 and cin in (64, 128) and PROJ_BN_MFMA
+        dx_out = grad_slot_tensor(ctx.gslot) if (ctx.gslot is not None and ctx.needs_input_grad[0]) else None
         nb = L.proj_group_bwd_weight_bn_mfma_blocks(P) if mfma else L.proj_group_blocks(P)
         slab, bslab = _f32(nb * tot * cin, dev), _f32(nb * tot, dev)
         if mfma:
@@ -1068,11 +1119,11 @@ class FusedConvBNProjFn(torch.autograd.Function):
             L.bn_bwd_finalize(part.data_ptr(), nblk, Ct, P, dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stats[4].data_ptr(), stats[5].data_ptr(), st)
             dy = nhwc_empty(B, Ct, H, W, dtype, dev)
             L.proj_group_bn_bwd(1, *args, stats[4].data_ptr(), stats[5].data_ptr(), act, None, 0, dy.data_ptr(), Ct, P, Ct, st)
-            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, None, ctx.needs_input_grad[0], False, None, pre=(dy, dgb))
+            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, None, ctx.needs_input_grad[0], False, None, pre=(dy, dgb), dx_out=dx_out)
         else:
             dz = nhwc_empty(B, Ct, H, W, dtype, dev)
             L.proj_group_bwd_data(dt, n, cin, dout.data_ptr(), dout.stride(3), c_off, c_w, c_co, dz.data_ptr(), Ct, P, st)
-            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None)
+            dx, dW, dg, db, _ = _cba_backward(ctx.cfg, saved, dz, ctx.needs_input_grad[0], False, None, dx_out=dx_out)
         dWs, dgs, dbs_s, off = [], [], [], 0
         for co in ctx.couts_stack:
             dWs.append(dW[off:off + co])

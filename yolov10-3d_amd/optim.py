@@ -112,12 +112,26 @@ class FusedSGD:
         self._state = st
         return st
 
+    def set_hyper(self):
+        """write the groups' current lr / weight_decay into the EXISTING device tables (in place: a captured hipGraph of the step keeps
+        reading them, graph.GraphedTrainStep) - what a scheduler's `param_group["lr"] = ...` needs before the next replay"""
+        st = self._state
+        if st is None:
+            return
+        lr_all = [g["lr"] for g in self.param_groups for _ in g["params"]]
+        wd_all = [g["weight_decay"] for g in self.param_groups for _ in g["params"]]
+        st["lr"].copy_(torch.tensor([lr_all[i] for i in st["active"]], dtype=torch.float32), non_blocking=False)
+        st["wd"].copy_(torch.tensor([wd_all[i] for i in st["active"]], dtype=torch.float32), non_blocking=False)
+        st["hkey"] = [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups]
+
     def _tables(self):
         active = [i for i, p in enumerate(self.params) if p.grad is not None]
         if not active:
             raise Y3DError("FusedSGD.step: no parameter has a gradient")
         st = self._state
         hkey = [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups]
+        if st is not None and st["active"] == active and st["hkey"] != hkey and [h[2] for h in st["hkey"]] == [h[2] for h in hkey]:
+            self.set_hyper()  # only the values moved (a scheduler): same tables, new contents
         if st is None or st["active"] != active or st["hkey"] != hkey:
             st = self._build(active)
         pkey = [self.params[i].data_ptr() for i in active]
