@@ -90,6 +90,11 @@ BENCH_SHAPES = [
     (32, 64, 1, 21, 27, 3),         # ragged tiles both ways
     (64, 24, 1, 24, 40, 1),         # output channels not a multiple of 16
     (64, 48, 1, 16, 16, 2),         # three output-channel tiles; fewer tiles than partial-sum rows
+    # round 3: input channel counts that are not a multiple of the 32-channel K slab (X widths) on the persistent kernel
+    (80, 80, 1, 40, 40, 3),         # 80 -> 80: 2.5 slabs
+    (72, 160, 1, 24, 24, 2),        # 72 = 2 slabs + 8 channels, two output-channel tiles
+    (160, 160, 2, 16, 32, 2),       # two groups of 80 -> 80
+    (48, 96, 1, 16, 16, 4),         # 1.5 slabs, Cout > 64 (the narrow kernel does not take it)
 ]
 
 

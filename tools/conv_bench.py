@@ -23,6 +23,8 @@ SHAPES = [  # B, H, W, Cin, Cout, k, s, g
     (32, 40, 40, 2048, 384, 1, 1, 16),
     (32, 320, 320, 32, 64, 3, 2, 1),      # first backbone downsample: narrow stride-2 (the data gradient is latency-bound)
     (32, 160, 160, 64, 128, 3, 2, 1),
+    (16, 160, 160, 80, 80, 3, 1, 1),      # X widths: 2.5 K slabs on the persistent kernel (round 3)
+    (16, 80, 80, 160, 160, 3, 1, 1),
 ]
 
 def main():

@@ -103,7 +103,8 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
   const int wc = wave & 1, wp = wave >> 1;
   const int wl = wave & 3;                 // index inside the loader group
   const int wimg = wp / WPI, wrow0 = (wp % WPI) * 8;
-  const int nslab = p.Cg >> 5;             // >= 2 (launcher)
+  const int nslab = (p.Cg + 31) >> 5;      // >= 2 (launcher); Cg % 32 != 0 (80 channels of the X widths): the last slab's chunks past Cg are
+                                           // zeros on both operands (out-of-range DMA lanes)
 
   // ---- persistent schedule ------------------------------------------------------------------------------------------------------
   const int ntiles = p.G * p.nbt * p.nty * p.ntx * p.ntc;
@@ -154,8 +155,9 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
     const bool wrap = t >= HWD;
     const int hx = t - (wrap ? HWD : 0);
     const bool xok = (unsigned)(c.x0 - 1 + hx) < (unsigned)p.W;
-    const bool ok = iok & xok & (wrap ? y1ok : y0ok);
-    const unsigned off = (unsigned)(sbase + __mul24(hx, xsw2) + (wrap ? xsh2 : 0) + (ls16 ^ ((hx & 4) << 3)));
+    const int pc = ls16 ^ ((hx & 4) << 3);           // 16 x the piece this lane fetches = 2 x its first channel inside the slab
+    const bool ok = iok & xok & (wrap ? y1ok : y0ok) & (pc < (p.Cg - slab * 32) * 2);
+    const unsigned off = (unsigned)(sbase + __mul24(hx, xsw2) + (wrap ? xsh2 : 0) + pc);
     char* dst = sH + bufo + (img * NPIX + q * 16) * 64;
     if (q == IPI - 1 && NPIX % 16 != 0) {  // the partial instruction of an image: the lanes past its last pixel must not write LDS
       if (lj < NPIX - (IPI - 1) * 16)
@@ -167,16 +169,17 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
   // ---- weight DMA: two instructions per tap (128 rows x 64 B); lane -> row n = rd * 64 + (ltid >> 2) of the tile, piece s; rows
   // swizzled by piece ^= 2 * bit4(n).  Per-lane byte offsets inside the tap computed once.
   const int ltid = tid & 255;
-  int wrel0, wrel1;
+  int wrel0, wrel1, wch;  // wch: first channel (inside a slab) of the piece this lane fetches - the same for both rows (bit 4 of n and n + 64 agree)
   {
     const int n0 = ltid >> 2, s = ltid & 3;
-    wrel0 = (n0 * p.Ktot + ((s ^ (((n0 >> 4) & 1) << 1)) << 3)) * 2;
-    wrel1 = ((n0 + 64) * p.Ktot + ((s ^ ((((n0 + 64) >> 4) & 1) << 1)) << 3)) * 2;
+    wch = (s ^ (((n0 >> 4) & 1) << 1)) << 3;
+    wrel0 = (n0 * p.Ktot + wch) * 2;
+    wrel1 = ((n0 + 64) * p.Ktot + wch) * 2;
   }
   auto issue_w = [&](const TileC& c, int slab, int tap, int slot, int rd) {
     const unsigned base = (unsigned)((c.g * p.Cn + c.c0) * p.Ktot + (p.flip ? 8 - tap : tap) * p.Cg + slab * 32) * 2u;
     const int n = rd * 64 + (ltid >> 2);
-    const bool ok = (c.live != 0) & (c.c0 + n < p.Cn);
+    const bool ok = (c.live != 0) & (c.c0 + n < p.Cn) & (wch < p.Cg - slab * 32);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sW + slot * WB + (rd * 256 + wl * 64) * 16), 16,
                                              ok ? base + (unsigned)(rd ? wrel1 : wrel0) : OOB, 0, 0, 0);
   };
@@ -488,6 +491,7 @@ int y3d_conv3x3_wide3_launch(int th, const void* x, long xsb, long xsh, long xsw
   const unsigned long wb = (unsigned long)G * Cn * Ktot * 2;
   Y3D_CHECK(xb < 0xfffffff0ul && wb < 0xfffffff0ul, "conv3x3_wide: operand larger than 4 GB");
   Y3D_CHECK(2 * xsw < (1L << 23) && Ktot < (1 << 22), "conv3x3_wide: pixel stride beyond the 24-bit address multiply");
+  Y3D_CHECK(Cg % 8 == 0 && Cg >= 40 && Cn % 16 == 0, "conv3x3_wide: Cg = %d must be a multiple of 8, at least 40 (two K slabs); Cn = %d a multiple of 16", Cg, Cn);
   p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   if (th == 16) return scale ? launch_wide3<16, 1>(p, st) : launch_wide3<16, 0>(p, st);

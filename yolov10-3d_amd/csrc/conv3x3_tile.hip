@@ -340,7 +340,10 @@ static int v2_max_tiles() {
 int y3d_tile_height(int dtype, int B, int H, int W, int Cg, int Cn, int G, int kh, int kw, int stride, int pad) {
   int cse = 32;  // channels per K slab: 32 bf16 (64-byte rows, wide kernel) or 32 fp32 (128-byte rows)
   if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return 0;
-  if (Cg % cse != 0 || Cg < 64 || Cn % 16 != 0) return 0;
+  // bf16: the persistent kernel (conv3x3_wide3.hip) zero-fills a partial last 32-channel slab: any multiple of 8 from 40 channels
+  // on (80 -> 80 of the X widths ran on the generic implicit GEMM: 270 TFLOP/s); the fp32 tile kernel keeps whole slabs
+  if (dtype == Y3D_BF16 ? (Cg % 8 != 0 || Cg < 40 || (Cg < 64 && Cg % 32 != 0 && Cn <= 64)) : (Cg % cse != 0 || Cg < 64)) return 0;
+  if (Cn % 16 != 0) return 0;
   if (W < 8) return 0;
   if (H % 16 == 0) return 16;
   if (H % 8 == 0) return 8;
@@ -366,7 +369,7 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
     const long wide_tiles = (long)G * cdiv(B, 32 / th) * p.nty * p.ntx * p.ntc;
     if (wide_tiles < v2_max_tiles() && Cg % 64 == 0 && H % th == 0)  // this kernel's K slab is a 128-byte row: 64 bf16 channels
       return th == 16 ? launch_tile_epi<bf16_t, 16>(p, st) : launch_tile_epi<bf16_t, 8>(p, st);
-    if (wide_v2()) return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
+    if (wide_v2() && Cg % 32 == 0 && Cg >= 64) return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
     return y3d_conv3x3_wide3_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
   }
   return th == 16 ? launch_tile_epi<float, 16>(p, st) : launch_tile_epi<float, 8>(p, st);
