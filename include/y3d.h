@@ -72,6 +72,13 @@ int y3d_conv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t x
 int y3d_conv2d_fwd_affine(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
                           const void* w_packed, const float* scale, const float* shift, int act, void* y, int64_t ysw, int Ho, int Wo,
                           int Cout, int groups, int kh, int kw, int stride, int pad, void* stream);
+/* the same with the residual of a shortcut block added AFTER the activation: y = act(conv(x, w) * scale + shift) + res
+ * (Bottleneck.forward in eval mode, block.py:342).  Only geometries for which y3d_conv2d_fwd_affine_res_ok returns 1 (bf16 3x3 s1 p1,
+ * <= 64 input and output channels: the narrow resident-weight kernel); other callers run y3d_conv2d_fwd + y3d_bn_act_fwd. */
+int y3d_conv2d_fwd_affine_res_ok(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
+int y3d_conv2d_fwd_affine_res(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                              const void* w_packed, const float* scale, const float* shift, int act, const void* res, int64_t rsw, void* y,
+                              int64_t ysw, int Ho, int Wo, int Cout, int groups, int kh, int kw, int stride, int pad, void* stream);
 /* dx = conv_transpose(dy, w)  (F.conv2d backward w.r.t. input) */
 int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
                         const void* w_packed_dgrad, void* dx, int64_t xsw, int H, int W, int Cin, int groups, int kh, int kw,

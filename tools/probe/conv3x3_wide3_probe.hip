@@ -376,7 +376,12 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
               s2[h][c2 * 2 + jj] += r;
               q2[h][c2 * 2 + jj] = __builtin_elementwise_fma(r, r, q2[h][c2 * 2 + jj]);
             }
+#ifdef Y3D_W3_NTSTORE
+          typedef unsigned u4v __attribute__((ext_vector_type(4)));
+          if (pok && cok[h]) __builtin_nontemporal_store((u4v){pk[0], pk[1], pk[2], pk[3]}, (u4v*)(dst + h * 32));
+#else
           if (pok && cok[h]) *(uint4*)(dst + h * 32) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#endif
         }
       }
     } else {

@@ -20,6 +20,9 @@ struct SmP {
   const bf16_t* w;   // [Cout][Ktot], K index = tap * Cin + ci (forward packing, or the dgrad packing of the transposed conv)
   bf16_t* y;
   float* part;       // [rows][Cout][2] or null
+  const float *scale, *shift;  // eval: y = act(conv * scale[c] + shift[c]) (+ res), no partial sums
+  const bf16_t* res;           // optional residual added after the activation (Bottleneck shortcut, block.py:342), pixel stride rsw
+  int act, rsw;
   int xsb, xsh, xsw, ysw;
   int B, H, W, Cin, Cout, Ktot, flip, rows;
   int nty, ntx, ntiles;
@@ -34,7 +37,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned sm_u32x2;
 // for 64-byte rows.
 template <int CB> __device__ __forceinline__ int sm_swz(int row) { return CB == 128 ? (row & 7) : ((row >> 2) & 3); }
 
-template <int CB, int NCT>  // NCT: 16-channel output tiles (Cout <= 16 NCT)
+template <int CB, int NCT, bool AFF>  // NCT: 16-channel output tiles (Cout <= 16 NCT); AFF: folded BatchNorm + SiLU (+ residual) epilogue
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   constexpr int TH = 8, HW = 18, NPIX = (TH + 2) * HW;          // 180 halo pixels
   constexpr int SPI = 1024 / CB;                                // pixel slots per DMA instruction (8 or 16)
@@ -149,10 +152,28 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
       for (int a = 0; a < NCT; ++a) {
         const int co = a * 16 + 4 * lq;
         float v[4];
+        if (AFF) {
+          // (the per-channel constants and the residual are ordinary loads: the compiler waits vmcnt(0) for them, which drains the halo
+          // prefetch once per tile - the eval forward is launch-bound, not bound by this kernel)
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.res && inb && co < p.Cout) {
+            const uint2 rr = *(const uint2*)(p.res + (long)((b * p.H + yy) * p.W + xx) * p.rsw + co);
+            rv[0] = __uint_as_float(rr.x << 16); rv[1] = __uint_as_float(rr.x & 0xffff0000u);
+            rv[2] = __uint_as_float(rr.y << 16); rv[3] = __uint_as_float(rr.y & 0xffff0000u);
+          }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = bf2f(f2bf(acc[r][a][j]));
-          if (inb) { ssum[a][j] += v[j]; ssq[a][j] += v[j] * v[j]; }
+          for (int j = 0; j < 4; ++j) {
+            float u = acc[r][a][j];
+            if (co + j < p.Cout) u = u * p.scale[co + j] + p.shift[co + j];
+            if (p.act) u = silu_f(u);
+            v[j] = u + rv[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = bf2f(f2bf(acc[r][a][j]));
+            if (inb) { ssum[a][j] += v[j]; ssq[a][j] += v[j] * v[j]; }
+          }
         }
         const sm_u32x2 u = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
         __builtin_amdgcn_raw_buffer_store_b64(u, ry, (inb & (co < p.Cout)) ? (pix + co) * 2u : OOB, 0, 0);
@@ -186,16 +207,16 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   }
 }
 
-template <int CB, int NCT>
+template <int CB, int NCT, bool AFF>
 void sm_launch(const SmP& p, int grid, hipStream_t st) {
   constexpr int SPI = 1024 / CB, NINST = (180 + SPI - 1) / SPI, NI = (NINST + 3) / 4;
   const size_t lds = (size_t)9 * NCT * 16 * CB + 2 * (size_t)NI * 4 * 1024;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT, AFF>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -218,7 +239,8 @@ int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout) {
 }
 
 int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
-                             long ysw, float* part, int rows, int flip, void* stream) {
+                             long ysw, float* part, int rows, int flip, const float* scale, const float* shift, int act, const void* res, long rsw,
+                             void* stream) {
   Y3D_CHECK(((uintptr_t)x & 15) == 0 && xsb % 8 == 0 && xsh % 8 == 0 && xsw % 8 == 0 && ((uintptr_t)w & 15) == 0 && Ktot % 8 == 0 &&
                 ((uintptr_t)y & 7) == 0 && ysw % 4 == 0, "conv3x3_small: operand alignment");
   const long xext = ((long)(B - 1) * xsb + (long)(H - 1) * xsh + (long)(W - 1) * xsw + Cin) * 2;
@@ -227,6 +249,9 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
             "conv3x3_small: tensors beyond 32-bit byte offsets");
   SmP p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.part = part;
+  p.scale = scale; p.shift = shift; p.act = act; p.res = (const bf16_t*)res; p.rsw = (int)rsw;
+  Y3D_CHECK(!(scale && part) && (scale || !res), "conv3x3_small: the affine epilogue carries no BatchNorm partials; a residual needs the affine form");
+  Y3D_CHECK(!res || (((uintptr_t)res & 7) == 0 && rsw % 4 == 0 && (long)B * H * W * rsw < (1L << 31)), "conv3x3_small: residual alignment");
   p.xsb = (int)xsb; p.xsh = (int)xsh; p.xsw = (int)xsw; p.ysw = (int)ysw;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ktot = Ktot; p.flip = flip; p.rows = rows;
   p.nty = cdiv(H, 8); p.ntx = cdiv(W, 16); p.ntiles = B * p.nty * p.ntx;
@@ -238,14 +263,15 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
   const int grid = y3d_conv3x3_small_rows(B, H, W, Cin, Cout);
   Y3D_CHECK(!part || rows == grid, "conv3x3_small: the partial buffer must have y3d_conv2d_stat_rows rows (%d given, %d written)", rows, grid);
   hipStream_t st = (hipStream_t)stream;
-#define SM_GO(CB)                                                   \
-  switch (nct) {                                                    \
-    case 1: sm_launch<CB, 1>(p, grid, st); break;                   \
-    case 2: sm_launch<CB, 2>(p, grid, st); break;                   \
-    case 3: sm_launch<CB, 3>(p, grid, st); break;                   \
-    default: sm_launch<CB, 4>(p, grid, st); break;                  \
+#define SM_GO(CB, AFF)                                                   \
+  switch (nct) {                                                         \
+    case 1: sm_launch<CB, 1, AFF>(p, grid, st); break;                   \
+    case 2: sm_launch<CB, 2, AFF>(p, grid, st); break;                   \
+    case 3: sm_launch<CB, 3, AFF>(p, grid, st); break;                   \
+    default: sm_launch<CB, 4, AFF>(p, grid, st); break;                  \
   }
-  if (cb == 128) { SM_GO(128) } else { SM_GO(64) }
+  if (scale) { if (cb == 128) { SM_GO(128, true) } else { SM_GO(64, true) } }
+  else { if (cb == 128) { SM_GO(128, false) } else { SM_GO(64, false) } }
 #undef SM_GO
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;

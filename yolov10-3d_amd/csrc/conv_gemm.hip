@@ -772,7 +772,8 @@ int y3d_conv3x3s2_dgrad_launch(const void* dy, long dsw, int B, int Ho, int Wo, 
 // conv3x3_small.hip
 int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int rows);
 int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
-                             long ysw, float* part, int rows, int flip, void* stream);
+                             long ysw, float* part, int rows, int flip, const float* scale, const float* shift, int act, const void* res, long rsw,
+                             void* stream);
 int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout);
 int y3d_conv1x1_stream_rows(long M, int K, int N, int G = 1);
 extern "C" int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
@@ -872,7 +873,8 @@ static int check_align(const char* what, const void* ptr, long s0, long s1, long
 
 static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
                            const void* w_packed, const float* bias, const float* scale, const float* shift, int act, void* y, int64_t ysw,
-                           int Ho, int Wo, int Cout, int groups, int kh, int kw, int stride, int pad, float* stat_partials, void* stream) {
+                           int Ho, int Wo, int Cout, int groups, int kh, int kw, int stride, int pad, float* stat_partials, void* stream,
+                           const void* res = nullptr, int64_t rsw = 0) {
   int ce = dtype == Y3D_BF16 ? 8 : 4;
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "conv2d_fwd: bad dtype %d", dtype);
   Y3D_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && groups > 0, "conv2d_fwd: empty shape");
@@ -899,11 +901,12 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
   // pixel-dense, or beyond 32-bit byte offsets) must not fall through to the generic kernel's one-row-per-tile layout
   Y3D_CHECK(!(stat_partials && kh == 1 && kw == 1 && stride == 1 && pad == 0 && y3d_conv1x1_stream_ok(dtype, p.M, p.Cg, p.Cn, Cin, groups)),
             "conv2d_fwd: 1x1 input view must be pixel-dense and below 4 GB for the BatchNorm partial layout of this shape");
-  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && !bias && !scale) {
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && !bias) {
     const int rows = stat_partials ? y3d_conv2d_stat_rows(dtype, B, H, W, Cin, Cout, groups, kh, kw, stride, pad) : 1;
     if (y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, rows))
-      return y3d_conv3x3_small_launch(x, xsb, xsh, xsw, B, H, W, Cin, Cout, w_packed, p.Ktot, y, ysw, stat_partials, rows, 0, stream);
+      return y3d_conv3x3_small_launch(x, xsb, xsh, xsw, B, H, W, Cin, Cout, w_packed, p.Ktot, y, ysw, stat_partials, rows, 0, scale, shift, act, res, rsw, stream);
   }
+  Y3D_CHECK(!res, "conv2d_fwd_affine_res: no kernel with a residual epilogue takes this geometry (ask y3d_conv2d_fwd_affine_res_ok first)");
   if (!bias && g_tile_kernels) {
     int th = y3d_tile_height(dtype, B, H, W, p.Cg, p.Cn, groups, kh, kw, stride, pad);
     if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, scale, shift, act, stream);
@@ -925,6 +928,19 @@ int y3d_conv2d_fwd_affine(int dtype, const void* x, int64_t xsb, int64_t xsh, in
   Y3D_CHECK(scale && shift, "conv2d_fwd_affine: scale/shift required");
   return conv2d_fwd_impl(dtype, x, xsb, xsh, xsw, B, H, W, Cin, w_packed, nullptr, scale, shift, act, y, ysw, Ho, Wo, Cout, groups, kh, kw,
                          stride, pad, nullptr, stream);
+}
+
+int y3d_conv2d_fwd_affine_res_ok(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad) {
+  return kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, 1);
+}
+
+int y3d_conv2d_fwd_affine_res(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
+                              const void* w_packed, const float* scale, const float* shift, int act, const void* res, int64_t rsw, void* y,
+                              int64_t ysw, int Ho, int Wo, int Cout, int groups, int kh, int kw, int stride, int pad, void* stream) {
+  Y3D_CHECK(scale && shift && res, "conv2d_fwd_affine_res: scale / shift / residual required");
+  Y3D_CHECK(y3d_conv2d_fwd_affine_res_ok(dtype, B, H, W, Cin, Cout, groups, kh, kw, stride, pad), "conv2d_fwd_affine_res: geometry not supported");
+  return conv2d_fwd_impl(dtype, x, xsb, xsh, xsw, B, H, W, Cin, w_packed, nullptr, scale, shift, act, y, ysw, Ho, Wo, Cout, groups, kh, kw,
+                         stride, pad, nullptr, stream, res, rsw);
 }
 
 int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int Cout,
@@ -949,7 +965,7 @@ int y3d_conv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int
       y3d_conv1x1_stream_ok(dtype, p.M, p.Cg, p.Cn, dsw, groups))
     return y3d_conv1x1_stream_launch(dy, dsw, w_packed_dgrad, p.Kpad, nullptr, nullptr, nullptr, 0, dx, xsw, nullptr, p.M, p.Cg, p.Cn, groups, stream);
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && Ho == H && Wo == W && y3d_conv3x3_small_ok(dtype, B, H, W, Cout, Cin, 1))
-    return y3d_conv3x3_small_launch(dy, dsb, dsh, dsw, B, H, W, Cout, Cin, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, 1, stream);
+    return y3d_conv3x3_small_launch(dy, dsb, dsh, dsw, B, H, W, Cout, Cin, w_packed_dgrad, p.Kpad, dx, xsw, nullptr, 1, 1, nullptr, nullptr, 0, nullptr, 0, stream);
   if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && dense_pixels(B, Ho, Wo, dsb, dsh, dsw) &&
       y3d_conv3x3s2_dgrad_ok(dtype, B, Ho, Wo, H, W, Cout, Cin, dsw, xsw))
     return y3d_conv3x3s2_dgrad_launch(dy, dsw, B, Ho, Wo, Cout, w_packed_dgrad, p.Kpad, dx, xsw, H, W, Cin, stream);

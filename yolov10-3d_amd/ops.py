@@ -510,6 +510,14 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                    lambda: L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss_eval[0].data_ptr(), ss_eval[1].data_ptr(),
                                                int(act), ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st))
             return ye, None, None
+        if (not training and res_mode == 1 and dtype == torch.bfloat16
+                and L.conv2d_fwd_affine_res_ok(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)):
+            # eval Bottleneck shortcut: conv + folded BatchNorm + SiLU + residual in ONE launch (the narrow resident-weight kernel)
+            rr = to_nhwc(res, dtype, dense=True)
+            ye = out_tensor(B, Cout, Ho, Wo, dtype, dev)
+            L.conv2d_fwd_affine_res(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss_eval[0].data_ptr(), ss_eval[1].data_ptr(), int(act),
+                                    rr.data_ptr(), rr.stride(3), ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st)
+            return ye, None, None
         if not training:
             pass  # eval with a residual: conv (cached packed weights) + one BatchNorm / SiLU / residual pass below
         elif pack_cache and training and PACK_CACHE:
