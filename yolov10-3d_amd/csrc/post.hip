@@ -9,39 +9,71 @@
 
 namespace {
 
+// (value desc, index asc) arg-max exchange steps on the VALU: DPP swizzles inside a 16-lane row, gfx950 row swaps across rows - no LDS
+// crossbar (`__shfl_xor` = ds_bpermute: twelve dependent ~100-cycle round trips per winner in the first form of this reduction)
+__device__ __forceinline__ void amax_pick(float& v, int& i, float v2, int i2) {
+  const bool take = v2 > v || (v2 == v && i2 < i);
+  v = take ? v2 : v;
+  i = take ? i2 : i;
+}
+template <int CTRL> __device__ __forceinline__ void amax_dpp(float& v, int& i) {
+  const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  const int i2 = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, false);
+  amax_pick(v, i, v2, i2);
+}
+__device__ __forceinline__ void amax_row16(float& v, int& i) {  // every lane of a 16-lane row ends with the row's best
+  amax_dpp<0xB1>(v, i);   // quad_perm [1,0,3,2]
+  amax_dpp<0x4E>(v, i);   // quad_perm [2,3,0,1]
+  amax_dpp<0x141>(v, i);  // row_half_mirror
+  amax_dpp<0x140>(v, i);  // row_mirror
+}
+__device__ __forceinline__ void amax_wave(float& v, int& i) {  // every lane ends with the wave's best
+  amax_row16(v, i);
+  {
+    auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    auto ri = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
+    float a = __uint_as_float(rv[0]);
+    int ai = (int)ri[0];
+    amax_pick(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
+    v = a; i = ai;
+  }
+  {
+    auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    auto ri = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);
+    float a = __uint_as_float(rv[0]);
+    int ai = (int)ri[0];
+    amax_pick(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
+    v = a; i = ai;
+  }
+}
+
 // K times the block-wide arg-max of (value desc, index asc) over `n` LDS values, earlier winners excluded by overwriting them with -inf.
-// Every thread keeps the best of ITS strided subset in registers; a round is one wave reduction by shuffles, one LDS hand-off between
-// the (<= 16) waves - double-buffered, so ONE barrier per winner - and a rescan of the winner's subset by its owner thread only
-// (the first form rescanned all n values and took two barriers per winner: 175 us for the 6 400 cells of the stride-8 level).
-// sv / si: at least 2 * (blockDim.x / 64) entries each.
+// Every thread keeps the best of ITS strided subset in registers; a round is one wave reduction on the VALU (amax_wave), one LDS
+// hand-off between the (<= 16) waves - double-buffered, so ONE barrier per winner; every thread then reads ONE wave's entry and folds
+// the 16 of them inside its DPP row - and a rescan of the winner's subset by its owner thread only.  (First form: a rescan of all n
+// values, shuffles through the LDS crossbar, a serial fold of the waves and two barriers per winner: 2.8 us per winner, 277 us for the
+// postprocess of a batch of 32.)   sv / si: at least 32 entries each.
 __device__ void block_topk(float* vals, int n, int K, int* out_idx, float* out_val, float* sv, int* si) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  if (tid < 32) { sv[tid] = -INFINITY; si[tid] = 0x7fffffff; }  // entries of waves that do not exist never win
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   for (int a = tid; a < n; a += nt) {
     const float v = vals[a];
     if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
   }
+  __syncthreads();
   for (int j = 0; j < K; ++j) {
     float wv = bv;
     int wi = bi;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float v2 = __shfl_xor(wv, off);
-      const int i2 = __shfl_xor(wi, off);
-      if (v2 > wv || (v2 == wv && i2 < wi)) { wv = v2; wi = i2; }
-    }
-    float* svj = sv + (j & 1) * nw;
-    int* sij = si + (j & 1) * nw;
+    amax_wave(wv, wi);
+    float* svj = sv + (j & 1) * 16;
+    int* sij = si + (j & 1) * 16;
     if (lane == 0) { svj[wave] = wv; sij[wave] = wi; }
     __syncthreads();
-    float gv = svj[0];
-    int gi = sij[0];
-    for (int w = 1; w < nw; ++w) {
-      const float v2 = svj[w];
-      const int i2 = sij[w];
-      if (v2 > gv || (v2 == gv && i2 < gi)) { gv = v2; gi = i2; }
-    }
+    float gv = svj[lane & 15];
+    int gi = sij[lane & 15];
+    amax_row16(gv, gi);
     if (tid == 0) {
       out_idx[j] = gi < n ? gi : 0;
       if (out_val) out_val[j] = gv;
