@@ -256,9 +256,11 @@ int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, floa
  * scal[0] = max(sum(target_scores), 1), scal[1] = number of foreground anchors.
  * n = rows per image of gt (capacity, <= 64); n_used: device int from y3d_pad_targets (rows >= *n_used are padding in every
  * image and are skipped), or NULL = all n rows are walked.  The results do not depend on n_used. */
+/* mode (cfg/default.yaml:116-119 -> utils/tal.py:465-497): bit 0 `tal_2d` (box metric), bit 1 `tal_3d` (keypoint metric; at least one of
+ * the two), bit 2 `kps_dist_metric: l2` (else l1), bit 3 `constrain_anchors` (candidates inside the box only).  Default 1 | 2 | 8 = 11. */
 int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
                      int B, int nc, const float* gt, int n, const float* calib, const float* mean_sizes, int topk, float alpha,
-                     float beta, float gamma, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
+                     float beta, float gamma, int mode, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
                      const int* n_used, void* stream);
 /* items[6] = (box2d, cls, depth, offset3d, size3d, heading) of loss.py:886-891; grads[l] (pixel stride gsw[l]) receives
  * grad_scale * d(sum(items))/d(map) for all nc+35 channels.  partials: 6 * ceil(B*A/256) floats */

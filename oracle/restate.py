@@ -654,11 +654,15 @@ def tal2d(pd_scores, pd_bboxes, anc, gt_labels, gt_bboxes, mask_gt, topk, nc, al
 
 
 def tal3d(pd_scores, pd_bboxes, pd_3d, anc, gts, mask_gt, stride_tensor, calibs, mean_sizes, topk, nc,
-          alpha=0.5, beta=1.0, gamma=1.0, eps=1e-9):
-    """utils/tal.py:392-452 TaskAlignedAssigner3d.forward with use_2d = use_3d = True, kps 'l1', constrain_anchors
-    (cfg/default.yaml:112-119).  `gts` = (labels(B,n,1), bboxes xyxy px(B,n,4), center_2d, size_2d, center_3d,
-    size_3d residual, depth, heading_bin, heading_res).  Returns
-    (targets[9], fg_mask bool (B,A), target_gt_idx int64 (B,A))."""
+          alpha=0.5, beta=1.0, gamma=1.0, eps=1e-9, use_2d=True, use_3d=True, kps_dist="l1", constrain=True):
+    """utils/tal.py:392-452 TaskAlignedAssigner3d.forward.  Defaults = cfg/default.yaml:112-119 (use_2d = use_3d = True, kps 'l1',
+    constrain_anchors); the other modes follow tal.py:465-497: box-only metric (get_box_metrics, "overlaps" = CIoU), keypoint-only
+    (get_keypoint_metrics, "overlaps" = similarities), 'l2' keypoint distance 1 / exp(0.5 * sum(d^2) / 24), and candidates not
+    restricted to the anchors inside the box (`constrain_anchors: False`: the metric mask and mask_pos use mask_gt alone).
+    `gts` = (labels(B,n,1), bboxes xyxy px(B,n,4), center_2d, size_2d, center_3d, size_3d residual, depth, heading_bin, heading_res).
+    Returns (targets[9], fg_mask bool (B,A), target_gt_idx int64 (B,A))."""
+    if not (use_2d or use_3d):
+        raise RuntimeError("Either 2D or 3D assignment or both has to be selected!")  # tal.py:484
     gl, gb, gc2, gs2, gc3, gs3, gd, ghb, ghr = gts
     B, A = pd_scores.shape[:2]
     n = gb.shape[1]
@@ -670,14 +674,25 @@ def tal3d(pd_scores, pd_bboxes, pd_3d, anc, gts, mask_gt, stride_tensor, calibs,
     g_kps = keypoints_3d(gc3, gd, gs3_full, ghb, ghr, calibs)  # (B,n,8,3)
     p_kps = keypoints_3d(pc3, dep, ps3, hd[..., :12], hd[..., 12:], calibs)  # (B,A,8,3)
     in_g = _in_gts(anc, gb)
-    m = (in_g * mask_gt).bool()
+    gmask = (in_g * mask_gt) if constrain else mask_gt.expand(-1, -1, A)  # :476, 480, 483
+    m = gmask.bool()
     sc = pd_scores.gather(2, lab.clamp(min=0)[:, None, :].expand(-1, A, -1)).permute(0, 2, 1)
     sc = torch.where(m, sc, torch.zeros_like(sc))
-    dist = (p_kps[:, None] - g_kps[:, :, None]).abs().sum((-1, -2)) / 24  # :464-467
-    sim = torch.where(m, 1 / torch.exp(dist), torch.zeros_like(dist))
-    ov = torch.where(m, ciou(gb[:, :, None, :], pd_bboxes[:, None, :, :]).clamp(min=0), torch.zeros_like(dist))
-    align = sc.pow(alpha) * ov.pow(beta) * sim.pow(gamma)  # :602  (returns `similarities` as "overlaps", :603)
-    mask_pos = stable_topk_mask(align, topk, mask_gt) * in_g * mask_gt
+    diff = p_kps[:, None] - g_kps[:, :, None]
+    if kps_dist == "l1":
+        sim_all = 1 / torch.exp(diff.abs().sum((-1, -2)) / 24)  # :465-467
+    else:
+        sim_all = 1 / torch.exp(0.5 * (diff * diff).sum((-1, -2)) / 24)  # :468-470
+    sim = torch.where(m, sim_all, torch.zeros_like(sim_all))
+    ov = torch.where(m, ciou(gb[:, :, None, :], pd_bboxes[:, None, :, :]).clamp(min=0), torch.zeros_like(sim_all))
+    if use_2d and use_3d:
+        align, second = sc.pow(alpha) * ov.pow(beta) * sim.pow(gamma), sim  # :602-603 (returns `similarities` as "overlaps")
+    elif use_3d:
+        align, second = sc.pow(alpha) * sim.pow(gamma), sim  # :575-576
+    else:
+        align, second = sc.pow(alpha) * ov.pow(beta), ov  # :553-554
+    mask_pos = stable_topk_mask(align, topk, mask_gt) * gmask  # :488-497
+    sim = second
     gt_idx, fg, mask_pos = _resolve(mask_pos, sim)
     flat = gt_idx + torch.arange(B)[:, None] * n
     t_lab = lab.flatten()[flat].clamp(min=0)

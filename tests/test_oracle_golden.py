@@ -135,6 +135,24 @@ def test_tal3d(topk):
         close(a, b, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["box_only", "kps_only_l2", "both_l2", "both_unconstrained", "kps_only_unconstrained_top1"])
+def test_tal3d_non_default_modes(mode):
+    """cfg/default.yaml:116-119 (`tal_2d`, `tal_3d`, `kps_dist_metric`, `constrain_anchors`): the oracle against the reference's
+    TaskAlignedAssigner3d in its other modes (tests/golden/tal3d_modes.npz, oracle/make_golden_modes.py), inputs of tal3d_topk8"""
+    g = load_golden("tal3d_topk8")
+    m = load_golden("tal3d_modes")[mode]
+    u2, u3, l2, con, topk = [int(v) for v in m["mode"]]
+    gts = g["gt"].split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)
+    targets, fg, gi = RS.tal3d(g["pd_scores"], g["pd_bboxes"], g["pd_3d"], g["anc"] * g["stride"], gts, g["mask_gt"],
+                               g["stride"], g["calib"], g["mean_sizes"], topk, 3, use_2d=bool(u2), use_3d=bool(u3),
+                               kps_dist="l2" if l2 else "l1", constrain=bool(con))
+    assert torch.equal(fg, m["fg_mask"].bool())
+    assert torch.equal(gi, m["target_gt_idx"].long())
+    assert torch.equal(targets[0], m["target_labels"].long())
+    close(targets[1], m["target_scores"], rtol=1e-4, atol=1e-6)
+    assert int(fg.sum()) > 0
+
+
 def test_keypoints():
     g = load_golden("tal3d_topk8")
     gts = g["gt"].split((1, 4, 2, 2, 2, 3, 1, 1, 1), 2)

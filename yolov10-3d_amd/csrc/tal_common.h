@@ -69,7 +69,7 @@ __device__ __forceinline__ float ciou_f(const float* g, float x21, float y21, fl
 
 // one block per (b, g): k passes of arg-max with (value desc, index asc) order; cand[b][g][j] = anchor index or -1
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ align, const float* __restrict__ rec, int* __restrict__ cand,
-                                                   Levels L, int n, int k, const int* __restrict__ n_used, int lds_row) {
+                                                   Levels L, int n, int k, const int* __restrict__ n_used, int lds_row, int constrain) {
   __shared__ float sv[256];
   __shared__ int si[256];
   __shared__ int chosen[16];
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ ali
     ay = (hy + 0.5f) * L.stride[l];
     (void)st; (void)lvl;
     float d0 = ax - r[G_BOX], d1 = ay - r[G_BOX + 1], d2 = r[G_BOX + 2] - ax, d3 = r[G_BOX + 3] - ay;
-    out[threadIdx.x] = fminf(fminf(d0, d1), fminf(d2, d3)) > 1e-9f ? a : -1;
+    // (`constrain_anchors: False`, tal.py:492-496: mask_pos = mask_topk * mask_gt - every top-k candidate of a valid box counts)
+    out[threadIdx.x] = (!constrain || fminf(fminf(d0, d1), fminf(d2, d3)) > 1e-9f) ? a : -1;
   }
 }
 

@@ -300,7 +300,7 @@ int y3d_tal2d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   else hipLaunchKernelGGL(metric2d_kernel<float>, gm, dim3(256), sm, st, L, rec, align, ovl, n, alpha, beta, n_used);
   {
     const bool fits = (size_t)A * sizeof(float) <= 96 * 1024;  // the metric row in LDS (33.6 KB at 640x640; 1280x1280: 131 KB, global passes)
-    hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), fits ? (size_t)A * sizeof(float) : 0, st, align, rec, cand, L, n, topk, n_used, fits ? 1 : 0);
+    hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), fits ? (size_t)A * sizeof(float) : 0, st, align, rec, cand, L, n, topk, n_used, fits ? 1 : 0, 1);
   }
   int nblk = cdiv((long)B * A, 256);
   hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, ovl, fg_mask, target_gt_idx, pa, po, B, n, A, topk, n_used);

@@ -73,7 +73,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __restrict__ rec, const float* __restrict__ calib,
                                                      const float* __restrict__ mean_sizes, float* __restrict__ align,
                                                      float* __restrict__ sim, int n, float alpha, float beta, float gamma,
-                                                     const int* __restrict__ n_used) {
+                                                     const int* __restrict__ n_used, int mode) {
   extern __shared__ float sg[];  // [n][GTW]
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < n * GTW; i += blockDim.x) sg[i] = rec[(long)b * n * GTW + i];
@@ -113,20 +113,30 @@ __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __re
     const float* r = sg + g * GTW;
     float al = 0.f, sm = 0.f;
     if (r[G_VALID] != 0.f) {
-      // tal.py:709-726: anchor centre strictly inside the box (eps 1e-9)
+      // tal.py:709-726: anchor centre strictly inside the box (eps 1e-9); with `constrain_anchors: False` (mode bit 8 clear) the metric
+      // is computed for every anchor of a valid box (tal.py:476-483)
       float d0 = apx - r[G_BOX], d1 = apy - r[G_BOX + 1], d2 = r[G_BOX + 2] - apx, d3 = r[G_BOX + 3] - apy;
-      if (fminf(fminf(d0, d1), fminf(d2, d3)) > 1e-9f) {
+      if (!(mode & 8) || fminf(fminf(d0, d1), fminf(d2, d3)) > 1e-9f) {
         float s = sc[(int)r[G_LABEL]];
         float ov = fmaxf(ciou_f(r + G_BOX, bx1, by1, bx2, by2), 0.f);
         float dist = 0.f;
+        if (mode & 4) {  // kps_dist_metric "l2": 1 / exp(0.5 * sum(d^2) / 24)  (tal.py:468-470)
 #pragma unroll
-        for (int j = 0; j < 24; ++j) dist += fabsf(kp[j] - r[G_KPS + j]);
-        dist = dist / 24.f;
-        sm = 1.f / expf(dist);
+          for (int j = 0; j < 24; ++j) { const float d = kp[j] - r[G_KPS + j]; dist += d * d; }
+          dist = 0.5f * (dist / 24.f);
+        } else {         // "l1": 1 / exp(sum|d| / 24)  (tal.py:465-467)
+#pragma unroll
+          for (int j = 0; j < 24; ++j) dist += fabsf(kp[j] - r[G_KPS + j]);
+          dist = dist / 24.f;
+        }
+        const float smk = 1.f / expf(dist);
         float sa = alpha == 0.5f ? sqrtf(s) : (alpha == 1.f ? s : powf(s, alpha));
         float ob = beta == 1.f ? ov : powf(ov, beta);
-        float sgm = gamma == 1.f ? sm : powf(sm, gamma);
-        al = sa * ob * sgm;
+        float sgm = gamma == 1.f ? smk : powf(smk, gamma);
+        // tal.py:473-484: box + keypoint metric ("overlaps" = similarities), keypoint-only, or box-only ("overlaps" = CIoU)
+        if ((mode & 3) == 3) { al = sa * ob * sgm; sm = smk; }
+        else if (mode & 2) { al = sa * sgm; sm = smk; }
+        else { al = sa * ob; sm = ov; }
       }
     }
     align[((long)b * n + g) * L.A + a] = al;
@@ -342,12 +352,13 @@ int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, floa
 
 int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* psw, const int* H, const int* W, const float* strides,
                      int B, int nc, const float* gt, int n, const float* calib, const float* mean_sizes, int topk, float alpha,
-                     float beta, float gamma, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
+                     float beta, float gamma, int mode, float* scratch, uint8_t* fg_mask, int* target_gt_idx, float* target_scores, float* scal,
                      const int* n_used, void* stream) {
   Levels L;
   if (fill_levels(L, dtype, nl, maps, psw, nullptr, nullptr, H, W, strides, B, nc, nc + 35)) return Y3D_ERR_INVALID;
   Y3D_CHECK(n >= 1 && n <= 64, "tal3d_assign: 1..64 ground-truth boxes per image (got %d)", n);
   Y3D_CHECK(topk >= 1 && topk <= 16, "tal3d_assign: topk in 1..16");
+  Y3D_CHECK((mode & 3) != 0 && (mode & ~15) == 0, "tal3d_assign: mode = %d: either the box metric (1) or the keypoint metric (2) or both must be selected", mode);
   hipStream_t st = (hipStream_t)stream;
   const int A = L.A;
   float* rec = scratch;
@@ -361,11 +372,11 @@ int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   hipLaunchKernelGGL(gt_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, calib, mean_sizes, rec, B, n, nc);
   dim3 gm(cdiv(A, 256), B);
   size_t sm = (size_t)n * GTW * sizeof(float);
-  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used);
-  else hipLaunchKernelGGL(metric_kernel<float>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used);
+  if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used, mode);
+  else hipLaunchKernelGGL(metric_kernel<float>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used, mode);
   {
     const bool fits = (size_t)A * sizeof(float) <= 96 * 1024;  // the metric row in LDS (33.6 KB at 640x640; 1280x1280: 131 KB, global passes)
-    hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), fits ? (size_t)A * sizeof(float) : 0, st, align, rec, cand, L, n, topk, n_used, fits ? 1 : 0);
+    hipLaunchKernelGGL(topk_kernel, dim3(B * n), dim3(256), fits ? (size_t)A * sizeof(float) : 0, st, align, rec, cand, L, n, topk, n_used, fits ? 1 : 0, (mode & 8) ? 1 : 0);
   }
   int nblk = cdiv((long)B * A, 256);
   hipLaunchKernelGGL(resolve_kernel, dim3(nblk), dim3(256), 0, st, cand, align, sim, fg_mask, target_gt_idx, pa, po, B, n, A, topk, n_used);

@@ -84,7 +84,8 @@ def _loss3d_set(cfg, gt, n_used, calib, mean_sizes, map_ptrs, psw, grad_ptrs, gs
     """one head set on the HIP kernels: assignment + six loss items + gradient rows written at grad_ptrs (pixel stride gsw).
     -> (items[6], fg (B, A) uint8, gt_idx (B, A) int32, target_scores (B, A, nc))"""
     L = lib()
-    strides, nc, topk, alpha, beta, gamma, w = cfg
+    strides, nc, topk, alpha, beta, gamma, w = cfg[:7]
+    mode = cfg[7] if len(cfg) > 7 else 11  # assigner mode bits (include/y3d.h: y3d_tal3d_assign); default tal_2d | tal_3d | constrain_anchors, l1
     dt, st, nl = ops.code(dtype), ops.stream(), len(map_ptrs)
     A = sum(h * w_ for h, w_ in zip(Hs, Ws))
     n = gt.shape[1]
@@ -102,7 +103,7 @@ def _loss3d_set(cfg, gt, n_used, calib, mean_sizes, map_ptrs, psw, grad_ptrs, gs
     ts = torch.empty(B, A, nc, dtype=torch.float32, device=dev)
     scal = torch.empty(2, dtype=torch.float32, device=dev)
     L.tal3d_assign(dt, nl, c_maps, c_psw, c_H, c_W, c_st, B, nc, gt.data_ptr(), n, calib.data_ptr(), mean_sizes.data_ptr(), topk,
-                   alpha, beta, gamma, scratch.data_ptr(), fg.data_ptr(), gi.data_ptr(), ts.data_ptr(), scal.data_ptr(),
+                   alpha, beta, gamma, int(mode), scratch.data_ptr(), fg.data_ptr(), gi.data_ptr(), ts.data_ptr(), scal.data_ptr(),
                    n_used.data_ptr() if n_used is not None else None, st)
     nblk = (B * A + 255) // 256
     part = torch.empty(nblk * 6, dtype=torch.float32, device=dev)
@@ -193,8 +194,12 @@ class DDDetectionLoss:
         self.hyp = h
         self.stride = [float(s) for s in m.stride]
         self.nc, self.no = m.nc, m.no
-        if not (h.tal_2d and h.tal_3d and h.kps_dist_metric == "l1" and h.constrain_anchors):
-            raise NotImplementedError("only the default 2D+3D / l1 / constrained assignment (cfg/default.yaml:112-119) is built")
+        # assigner modes of cfg/default.yaml:116-119 (utils/tal.py:465-497), as the mode bits of y3d_tal3d_assign
+        if not (h.tal_2d or h.tal_3d):
+            raise RuntimeError("Either 2D or 3D assignment or both has to be selected!")  # the reference's message, tal.py:484
+        if h.kps_dist_metric not in ("l1", "l2"):
+            raise ValueError(f"kps_dist_metric {h.kps_dist_metric!r}: 'l1' or 'l2' (utils/tal.py:465-470)")
+        self.mode = (1 if h.tal_2d else 0) | (2 if h.tal_3d else 0) | (4 if h.kps_dist_metric == "l2" else 0) | (8 if h.constrain_anchors else 0)
         self.topk = tal_topk
         if getattr(h, "distillation", False):
             raise NotImplementedError("distillation needs the DINOv2 teacher (network); pinned off (SURVEY §0.5)")
@@ -230,7 +235,7 @@ class DDDetectionLoss:
     def cfg(self, nl):
         h = self.hyp
         return (self.stride[:nl], self.nc, self.topk, float(h.tal_alpha), float(h.tal_beta), float(h.tal_gamma),
-                (float(h.loss2d), float(h.cls), float(h.depth), float(h.offset3d), float(h.size3d), float(h.heading)))
+                (float(h.loss2d), float(h.cls), float(h.depth), float(h.offset3d), float(h.size3d), float(h.heading)), self.mode)
 
     @property
     def last_assignment(self):
