@@ -93,8 +93,9 @@ def build_spec(cfg: dict, ch: int = 3) -> dict:
             if m == "v10Detect3d":
                 k1 = d.get("kernel_size_1") or 3  # default fix, SURVEY §0.5
                 k2 = d.get("kernel_size_2") or 3
-                L.update(channels=d["channels"], nl=d.get("num_scales", 3), k1=k1, k2=k2)
-                for flag in ("dsconv", "use_predecessors", "deform", "common_head", "half_channels", "fgdm_predictor"):
+                L.update(channels=d["channels"], nl=d.get("num_scales", 3), k1=k1, k2=k2, dsconv=bool(d.get("dsconv")),
+                         half=bool(d.get("half_channels")), pred=bool(d.get("use_predecessors")))
+                for flag in ("deform", "common_head", "fgdm_predictor"):  # common_head: the reference's own forward fails (head3d_dense)
                     if d.get(flag):
                         raise NotImplementedError(f"{flag}=True is not used by any shipped yaml")
         else:
@@ -181,11 +182,20 @@ def init_state(spec: dict, seed: int = 0, randomize_bn: bool = True) -> Dict[str
             for hs in ("o2o_heads", "o2m_heads"):
                 for j, name in enumerate(HEAD3D_BRANCHES):
                     mid = L["channels"][name + "_c"]
+                    last = mid // 2 if L.get("half") else mid  # head.py:629-636
+                    extra = sum(outs[HEAD3D_BRANCHES.index(q_)] for q_ in HEAD3D_PREDECESSORS[name]) if L.get("pred") else 0  # head.py:597-605
                     for i in range(L["nl"]):
                         q = f"{p}.{hs}.{j}.{i}"
-                        _conv_keys(st, q + ".0", L["ch"][i], mid, L["k1"], gen=gen)
-                        _conv_keys(st, q + ".1", mid, mid, L["k2"], gen=gen)
-                        _plain_conv_keys(st, q + ".2", mid, outs[j], gen=gen)
+                        cin = L["ch"][i] + extra
+                        if L.get("dsconv"):  # head.py:645-650
+                            _conv_keys(st, q + ".0.0", cin, cin, L["k1"], g=cin, gen=gen)
+                            _conv_keys(st, q + ".0.1", cin, mid, 1, gen=gen)
+                            _conv_keys(st, q + ".1.0", mid, mid, L["k2"], g=mid, gen=gen)
+                            _conv_keys(st, q + ".1.1", mid, last, 1, gen=gen)
+                        else:
+                            _conv_keys(st, q + ".0", cin, mid, L["k1"], gen=gen)
+                            _conv_keys(st, q + ".1", mid, last, L["k2"], gen=gen)
+                        _plain_conv_keys(st, q + ".2", last, outs[j], gen=gen)
         elif t == "v10Detect":
             nc, ch = L["nc"], L["ch"]
             c2 = max(16, ch[0] // 4, 64)
@@ -319,27 +329,49 @@ def psa(ctx, p, x):
 
 
 # ---- v10Detect3d -----------------------------------------------------------------------
-def head3d_branch(ctx, q, x, k1, k2, pad=None, want_emb=False):
-    e = conv_bn_act(ctx, q + ".0", x, k1, pad=pad)
-    y = conv_bn_act(ctx, q + ".1", e, k2, pad=pad)
+HEAD3D_PREDECESSORS = {"cls": (), "o2d": (), "s2d": (), "o3d": ("cls",), "s3d": ("cls",), "hd": ("cls",), "dep": ("cls", "s3d"),
+                       "dep_un": ("cls", "s3d", "dep")}  # head.py:585-594
+HEAD3D_DEP_NORM = 65.0  # head.py:595
+
+
+def head3d_conv(ctx, q, x, k, dsconv, pad=None):
+    """head.py:645-650 build_conv: Conv(k), or with `dsconv` a depth-wise Conv(k) followed by a 1x1 Conv.  `pad` = 0 is the patch path's
+    override, which reaches a plain Conv only (head.py:706-708 looks at the branch's top-level layers)."""
+    if not dsconv:
+        return conv_bn_act(ctx, q, x, k, pad=pad)
+    y = conv_bn_act(ctx, q + ".0", x, k, g=x.shape[1])
+    return conv_bn_act(ctx, q + ".1", y, 1)
+
+
+def head3d_branch(ctx, q, x, k1, k2, pad=None, want_emb=False, dsconv=False):
+    """one branch of build_head (head.py:629-636); `half_channels` only changes the weight shapes"""
+    e = head3d_conv(ctx, q + ".0", x, k1, dsconv, pad)
+    y = head3d_conv(ctx, q + ".1", e, k2, dsconv, pad)
     y = plain_conv(ctx, q + ".2", y)
     return (y, e) if want_emb else y
 
 
 def head3d_dense(ctx, p, hs, xs, L):
-    """head.py:718-743 forward_feat (no predecessors / common head): per level cat of 8 branches; 'dep' embeddings :745-749."""
+    """head.py:718-743 forward_feat: per level cat of 8 branches; 'dep' embeddings :745-749.  L['pred'] (`use_predecessors`): a
+    branch's input is the level's map concatenated with the detached outputs of HEAD3D_PREDECESSORS, depth / 65 (:727-737);
+    L['dsconv'] as head3d_conv.  `common_head` is not restated: the reference's own forward_feat fails on it (:746 asserts three
+    layers per branch, build_small_head makes two)."""
     ys, embs = [], []
+    ds, pred = bool(L.get("dsconv")), bool(L.get("pred"))
     for i in range(L["nl"]):
-        outs = []
+        outs = {}
         emb = None
         for j, name in enumerate(HEAD3D_BRANCHES):
             q = f"{p}.{hs}.{j}.{i}"
+            xin = xs[i]
+            if pred and HEAD3D_PREDECESSORS[name]:
+                xin = torch.cat([xs[i]] + [(outs[k] / HEAD3D_DEP_NORM if k == "dep" else outs[k]).detach() for k in HEAD3D_PREDECESSORS[name]], 1)
             if name == "dep":
-                o, emb = head3d_branch(ctx, q, xs[i], L["k1"], L["k2"], want_emb=True)
+                o, emb = head3d_branch(ctx, q, xin, L["k1"], L["k2"], want_emb=True, dsconv=ds)
             else:
-                o = head3d_branch(ctx, q, xs[i], L["k1"], L["k2"])
-            outs.append(o)
-        ys.append(torch.cat(outs, 1))
+                o = head3d_branch(ctx, q, xin, L["k1"], L["k2"], dsconv=ds)
+            outs[name] = o
+        ys.append(torch.cat(list(outs.values()), 1))
         embs.append(emb)
     return ys, embs
 
@@ -360,10 +392,13 @@ def head3d_sparse(ctx, p, hs, xs, L, max_det=50):
     pad = ps // 2
     outs_ch = head3d_out_channels(L["nc"])
     ys = []
+    ds = bool(L.get("dsconv"))
+    if L.get("pred"):
+        raise RuntimeError("use_predecessors: the reference's patch path feeds the branches bare feature patches (head.py:709) - channel mismatch")
     for i in range(L["nl"]):
         x = xs[i]
         B, C, H, W = x.shape
-        cls = head3d_branch(ctx, f"{p}.{hs}.0.{i}", x, L["k1"], L["k2"])
+        cls = head3d_branch(ctx, f"{p}.{hs}.0.{i}", x, L["k1"], L["k2"], dsconv=ds)
         cand = head3d_select_candidates(cls, max_det)  # (B,K,2)
         xp = F.pad(x, (pad, pad, pad, pad))
         rows = cand[..., 0].reshape(-1)
@@ -374,7 +409,9 @@ def head3d_sparse(ctx, p, hs, xs, L, max_det=50):
         patches = patches.permute(0, 3, 1, 2).contiguous()  # (B*K, C, ps, ps)
         outs = [cls]
         for j in range(1, 8):
-            o = head3d_branch(ctx, f"{p}.{hs}.{j}.{i}", patches, L["k1"], L["k2"], pad=0)[:, :, 0, 0]  # (B*K, c)
+            # patch cell (0, 0): the centre's value when both convs run unpadded (5x5 -> 1x1); with `dsconv` the convs keep their padding
+            # and the 5x5 result is read at its corner, as the reference does (head3d_conv)
+            o = head3d_branch(ctx, f"{p}.{hs}.{j}.{i}", patches, L["k1"], L["k2"], pad=0, dsconv=ds)[:, :, 0, 0]  # (B*K, c)
             full = torch.zeros(B, outs_ch[j], H, W)
             # later candidates overwrite earlier ones only if duplicated (top-k indices are unique)
             full[bidx, :, rows, cols] = o

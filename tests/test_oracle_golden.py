@@ -120,6 +120,53 @@ def test_head3d_eval(tag):
     close(y, g["y"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["dsconv", "half", "ds_half", "pred", "pred_half"])
+def test_head3d_constructor_options_train(name):
+    """the non-default v10Detect3d switches (head.py:554-650, 727-737) against fixtures minted from the reference with each switch on
+    (oracle/make_golden_headopts.py): head maps, 'dep' embeddings, input gradients, parameter gradients, BatchNorm running statistics"""
+    g = load_golden(f"head3d_opt_{name}_train")
+    ds, half, common, pred = [int(v) for v in g["meta"]]
+    L = dict(nc=3, nl=2, k1=3, k2=3, dsconv=ds, pred=pred)
+    st = {k: v.clone() for k, v in g["state"].items()}
+    for k, v in st.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    xs = [x.clone().requires_grad_(True) for x in g["x"]]
+    out = RS.head3d(RS.Ctx(st, True), "model.0", xs, L, [8.0, 16.0])
+    for a, b in zip(out["one2many"] + out["one2one"], g["o2m"] + g["o2o"]):
+        close(a, b)
+    for a, b in zip(out["o2m_embs"] + out["o2o_embs"], g["o2m_embs"] + g["o2o_embs"]):
+        close(a, b)
+    sum((t * r).sum() for t, r in zip(out["one2many"] + out["one2one"], g["r"])).backward()
+    for a, b in zip(xs, g["dx"]):
+        close(a.grad, b, rtol=2e-4, atol=1e-4)
+    for k, gv in g["grads"].items():
+        close(st[k].grad, gv, rtol=2e-4, atol=2e-4)
+    for k, v in g["state_after"].items():
+        close(st[k].detach().float(), v.float(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["dsconv", "half", "ds_half"])
+def test_head3d_constructor_options_eval(name):
+    g = load_golden(f"head3d_opt_{name}_eval")
+    ds, half, common, pred = [int(v) for v in g["meta"]]
+    L = dict(nc=3, nl=2, k1=3, k2=3, dsconv=ds, pred=pred)
+    st = {k: v.clone() for k, v in g["state"].items()}
+    with torch.no_grad():
+        y, maps = RS.head3d(RS.Ctx(st, False), "model.0", [x.clone() for x in g["x"]], L, [8.0, 16.0])["one2one"]
+    for a, b in zip(maps, g["maps"]):
+        close(a, b)
+    close(y, g["y"], rtol=1e-4, atol=1e-4)
+
+
+def test_head3d_predecessors_have_no_eval_path():
+    """the reference's patch path raises on `use_predecessors` (channel mismatch, printed by make_golden_headopts.py); so does the oracle"""
+    g = load_golden("head3d_opt_pred_train")
+    L = dict(nc=3, nl=2, k1=3, k2=3, pred=1)
+    with pytest.raises(RuntimeError):
+        RS.head3d(RS.Ctx(dict(g["state"]), False), "model.0", [torch.zeros(1, 8, 8, 8), torch.zeros(1, 16, 8, 8)], L, [8.0, 16.0])
+
+
 @pytest.mark.parametrize("topk", [8, 1])
 def test_tal3d(topk):
     g = load_golden(f"tal3d_topk{topk}")

@@ -332,28 +332,60 @@ def _proj(branches, feats):
     return ops.HeadProjFn.apply(n, *feats, *[b.weight for b in branches], *[b.bias for b in branches])
 
 
+def _conv_over_cat(m, parts):
+    """Conv module `m` over the channel concatenation of `parts` when the total is not a whole number of 16-byte chunks (the
+    `use_predecessors` inputs: ch + 3 / 6 / 7 channels): input and weight are zero-padded along the input channels to the next chunk
+    multiple (zero weights on zero channels: the same sums), then the ordinary HIP conv -> BatchNorm -> SiLU sequence runs; autograd
+    slices the padded gradients back (plumbing around the kernels)."""
+    dt = ops.compute_dtype()
+    c = ops.ce(dt)
+    cin = sum(t.shape[1] for t in parts)
+    cp = (cin + c - 1) // c * c
+    parts = [t.to(dt) for t in parts]
+    if cp != cin:
+        B, _, H, W = parts[0].shape
+        parts.append(torch.zeros(B, cp - cin, H, W, dtype=dt, device=parts[0].device))
+    w = m.conv.weight if cp == cin else torch.nn.functional.pad(m.conv.weight, (0, 0, 0, 0, 0, cp - cin))
+    return ops.ConvBNActFn.apply(torch.cat(parts, 1), w, m.bn.weight, m.bn.bias, None, 0, m)
+
+
 class v10Detect3d(nn.Module):
-    """reference head.py:545-975 (dsconv / predecessors / common_head / half_channels / fgdm off, as in every shipped yaml)."""
+    """reference head.py:545-975.  The shipped yamls leave every constructor switch off; with `dsconv`, `half_channels` or
+    `use_predecessors` on, the head is built and run branch by branch (head.py:629-650, 718-743) on the same HIP ops - the
+    sibling-branch fusion of the default head does not apply.  Not available, with the reference's own state of these switches:
+    `common_head` (its training forward fails in the reference, head.py:745-746: three layers asserted, `build_small_head` makes two),
+    `use_predecessors` in eval mode (the reference's patch path, head.py:709, hands the branches bare feature patches: channel
+    mismatch), `deform` / `fgdm_predictor` (DCN / depth-predictor code outside the YOLOv10 path)."""
 
     max_det = 50
     dynamic = False
     export = False
     shape = None
     fused = True  # sibling-branch fusion of the training forward (set False for the per-branch reference form)
+    PREDECESSORS = {"cls": (), "o2d": (), "s2d": (), "o3d": ("cls",), "s3d": ("cls",), "hd": ("cls",), "dep": ("cls", "s3d"),
+                    "dep_un": ("cls", "s3d", "dep")}  # head.py:585-594
 
     def __init__(self, nc=80, ch=(), dsconv=False, channels=None, use_predecessors=False, detach_predecessors=True,
                  deform=False, common_head=False, num_scales=3, half_channels=False, fgdm_predictor=False,
                  kernel_size_1=3, kernel_size_2=3):
         super().__init__()
         assert channels is not None
-        for name, flag in (("dsconv", dsconv), ("use_predecessors", use_predecessors), ("deform", deform),
-                           ("common_head", common_head), ("half_channels", half_channels), ("fgdm_predictor", fgdm_predictor)):
+        for name, flag in (("deform", deform), ("fgdm_predictor", fgdm_predictor)):
             if flag:
                 raise NotImplementedError(f"{name}=True is not used by any shipped v10-3D yaml")
+        if common_head:
+            raise NotImplementedError("common_head=True: the reference's own training forward fails on it (head.py:745-746 asserts three "
+                                      "layers per branch, build_small_head makes two); there is no behaviour to reproduce")
+        if dsconv and use_predecessors:
+            raise NotImplementedError("dsconv with use_predecessors: depth-wise convs over ch + 3 / 6 / 7 channels have no 16-byte-chunk kernel")
         kernel_size_1 = 3 if kernel_size_1 is None else kernel_size_1  # reference bug: tasks.py:940 passes None (SURVEY §0.5)
         kernel_size_2 = 3 if kernel_size_2 is None else kernel_size_2
         self.nc = nc
         self.nl = num_scales
+        self.dsconv, self.half_channels = bool(dsconv), bool(half_channels)
+        self.use_predecessors, self.detach_predecessors = bool(use_predecessors), detach_predecessors
+        self.generic = self.dsconv or self.half_channels or self.use_predecessors  # branch-by-branch forward
+        self.predecessors = dict(self.PREDECESSORS)
         self.output_channels = {"cls": nc, "o2d": 2, "s2d": 2, "o3d": 2, "s3d": 3, "hd": 24, "dep": 1, "dep_un": 1}
         self.no = sum(self.output_channels.values())
         self.stride = torch.zeros(self.nl)
@@ -362,26 +394,47 @@ class v10Detect3d(nn.Module):
         self.dep_norm = 65.0
         ch = [ch[i] for i in range(self.nl)]
         for name, out in self.output_channels.items():
-            setattr(self, name, self.build_head(ch, channels[name + "_c"], out))
+            extra = sum(self.output_channels[q] for q in self.predecessors[name]) if self.use_predecessors else 0
+            setattr(self, name, self.build_head([c + extra for c in ch], channels[name + "_c"], out))
         self.o2o_heads = nn.ModuleList([self.cls, self.o2d, self.s2d, self.o3d, self.s3d, self.hd, self.dep, self.dep_un])
         self.o2m_heads = copy.deepcopy(self.o2o_heads)
 
     def build_head(self, in_channels, mid, out):
-        return nn.ModuleList(nn.Sequential(Conv(x, mid, self.kernel_size_1), Conv(mid, mid, self.kernel_size_2), nn.Conv2d(mid, out, 1))
-                             for x in in_channels)
+        last = mid // 2 if self.half_channels else mid
+        return nn.ModuleList(nn.Sequential(self.build_conv(x, mid, self.kernel_size_1, self.dsconv), self.build_conv(mid, last, self.kernel_size_2, self.dsconv),
+                                           nn.Conv2d(last, out, 1)) for x in in_channels)
+
+    @staticmethod
+    def build_conv(c1, c2, k, dsconv):
+        """head.py:645-650"""
+        return nn.Sequential(Conv(c1, c1, k, g=c1), Conv(c1, c2, 1)) if dsconv else Conv(c1, c2, k)
 
     # ---- dense (training) path: head.py:718-753 -------------------------------------------------------------
     def forward_feat(self, x, heads):
-        """per-branch form (one head set); kept for API parity with the reference, the training forward uses the fused form"""
+        """per-branch form (one head set): the reference's own loop, head.py:718-743.  The default head's training forward uses the fused
+        form below; the constructor switches run here."""
         ys, embs = [], []
+        names = list(self.output_channels)
         for i in range(self.nl):
-            feats, emb = [], None
+            feats, outs, emb = [], {}, None
             for j, module in enumerate(heads):
-                e = module[i][0](x[i])
+                br = module[i]
+                pre = self.predecessors[names[j]] if self.use_predecessors else ()
+                if pre:  # head.py:727-737: level map + detached earlier outputs (depth / 65) along the channels
+                    e = _conv_over_cat(br[0], [x[i]] + [(outs[q] / self.dep_norm if q == "dep" else outs[q]).detach() for q in pre])
+                else:
+                    e = br[0](x[i])
                 if j == 6:
                     emb = e
-                feats.append(module[i][1](e))
-            ys.append(_proj([module[i][2] for module in heads], feats))
+                if self.use_predecessors:
+                    outs[names[j]] = _proj([br[2]], [br[1](e)])
+                else:
+                    feats.append(br[1](e))
+            if self.use_predecessors:
+                dt = ops.compute_dtype()
+                ys.append(torch.cat([o.to(dt) for o in outs.values()], 1))
+            else:
+                ys.append(_proj([module[i][2] for module in heads], feats))
             embs.append(emb)
         return ys, embs
 
@@ -421,6 +474,8 @@ class v10Detect3d(nn.Module):
     def restack(self):
         """(re)establish the stacked parameter storage of the fused training forward now (e.g. before wrapping the model in
         DistributedDataParallel, after .to(device) / load_state_dict(assign=True) / deepcopy)"""
+        if self.generic:
+            return  # branch-by-branch head: every Conv keeps its own parameters
         for i in range(self.nl):
             _, _, s1, s2, parts, _ = self._stacks(i)
             s1.tensors()
@@ -502,6 +557,9 @@ class v10Detect3d(nn.Module):
         return idx
 
     def inference_forward_feat(self, x, heads):
+        if self.use_predecessors:
+            raise RuntimeError("use_predecessors has no eval path: the reference's patch forward (head.py:694-716) feeds the branches bare "
+                               "feature patches and fails on the channel count")
         ps = self.patch_size
         L = ops.lib()
         ys = []
@@ -517,7 +575,7 @@ class v10Detect3d(nn.Module):
             patches = ops.nhwc_empty(B * K, C, ps, ps, xi.dtype, xi.device)
             sb, sh, sw = ops.s3(xi)
             L.patch_gather(dt, xi.data_ptr(), sb, sh, sw, idx.data_ptr(), patches.data_ptr(), B, H, W, C, K, ps, st)
-            _, mids, s1, s2, _, _ = self._stacks(i)
+            _, mids, s1, s2, _, _ = self._stacks(i) if not self.generic else (None,) * 6
             if heads is self.o2o_heads and s2 is not None:
                 # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
                 # (channel rows mid..8*mid of the training-time stacks), both unpadded: patch semantics of head.py:706-708
@@ -535,12 +593,21 @@ class v10Detect3d(nn.Module):
                 feats = []
                 for j in range(1, 8):
                     br = heads[j][i]
-                    p0, p1 = br[0].conv.padding, br[1].conv.padding
-                    br[0].conv.padding, br[1].conv.padding = (0, 0), (0, 0)  # patch semantics: both convs unpadded (head.py:706-708)
+                    # patch semantics, head.py:706-708: the branch's TOP-LEVEL Conv layers run unpadded (5x5 patch -> 1x1); the nested
+                    # Sequentials of `dsconv` keep their padding there, and so here (the 5x5 result is then read at cell (0, 0) like the
+                    # reference reads it).  Unlike the reference we do not leave the modules mutated.
+                    convs = [l for l in list(br)[:-1] if isinstance(l, Conv)]
+                    pads = [l.conv.padding for l in convs]
+                    for l in convs:
+                        l.conv.padding = (0, 0)
                     try:
-                        feats.append(br[1](br[0](patches)))
+                        f = patches
+                        for l in list(br)[:-1]:
+                            f = l(f)
+                        feats.append(f)
                     finally:
-                        br[0].conv.padding, br[1].conv.padding = p0, p1  # unlike the reference we do not leave the module mutated
+                        for l, p0 in zip(convs, pads):
+                            l.conv.padding = p0
                 reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
             reg = reg.contiguous()
             full = ops.nhwc_empty(B, self.no, H, W, cls.dtype, xi.device)
@@ -567,13 +634,14 @@ class v10Detect3d(nn.Module):
         if not self.training:
             maps = self.inference_forward_feat([xi.detach() for xi in x], self.o2o_heads)
             return {"one2one": (self.decode(maps), maps), "o2o_embs": None}
-        if self.fused:
+        fused = self.fused and not self.generic
+        if fused:
             one2one, one2many, o2o_embs, o2m_embs = self.forward_train_fused(x)
         else:
             one2one, o2o_embs = self.forward_feat([xi.detach() for xi in x], self.o2o_heads)
             one2many, o2m_embs = self.forward_feat(x, self.o2m_heads)
         out = {"one2many": one2many, "one2one": one2one, "o2m_embs": o2m_embs, "o2o_embs": o2o_embs, "depth_maps": torch.empty(1)}
-        if self.fused:
+        if fused:
             out["_y3d_maps"] = self.__dict__.pop("_maps")  # private extra next to the reference's keys (head.py:833)
         return out
 
