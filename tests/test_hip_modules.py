@@ -819,6 +819,30 @@ def test_postprocess_hip_vs_reference_golden():
     check(sc, g["scores"], 1e-6, "post2d scores")
 
 
+@pytest.mark.parametrize("HW,K", [(400, 50), (1600, 50), (6400, 50), (25600, 50), (6400, 300), (64, 64), (1000, 1)])
+def test_topk_selection_ties_and_sizes(HW, K):
+    """the radix-select top-k of post.hip (`y3d_topk_cells`: select_candidates of the eval head; the same device function serves both
+    stages of `y3d_v10_postprocess`) against a stable descending sort - (value desc, index asc) - on inputs built to tie: logits on a
+    coarse grid (many exact ties around the K-th value), a constant map, -inf entries, signed zeros"""
+    from yolov10_3d_amd import ops
+    torch.manual_seed(HW + K)
+    B, nc = 6, 3
+    maps = torch.randn(B, HW, nc)
+    maps[0] = (maps[0] * 4).round() / 4          # coarse grid: hundreds of ties
+    maps[1] = 0.25                               # constant: the K lowest indices win
+    maps[2] = (maps[2] * 2).round() / 2
+    maps[2, ::3] = float("-inf")
+    maps[3] = torch.where(torch.rand(HW, nc) < 0.5, torch.zeros(()), -torch.zeros(()))  # +0 / -0 compare equal
+    maps[4] = -maps[4].abs() * 1e-3              # all negative, tiny
+    for dt in (torch.float32, torch.bfloat16):
+        m = maps.to(dt).to(DEV)
+        idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
+        ops.lib().topk_cells(ops.code(dt), m.data_ptr(), nc, B, HW, nc, K, idx.data_ptr(), ops.stream())
+        best = m.float().max(-1)[0].cpu() + 0.0
+        ref = torch.sort(best, dim=1, descending=True, stable=True)[1][:, :K]
+        assert torch.equal(idx.cpu().long(), ref), f"{dt}: rows {(idx.cpu().long() != ref).any(1).nonzero().flatten().tolist()} differ"
+
+
 def test_postprocess_hires_vs_oracle():
     """1280x1280 (33 600 anchors, BASELINE configs[3]): the score row does not fit LDS and goes through the HBM scratch"""
     from oracle import restate as RS

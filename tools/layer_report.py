@@ -1,5 +1,6 @@
 """Per-shape timing of every conv launch (forward / data gradient / weight gradient) of the training step, with the achieved
-TFLOP/s: which shapes cost the step the most.  usage (GPU box): python tools/layer_report.py [model.yaml] [imgsz] [batch]"""
+TFLOP/s: which shapes cost the step the most.  usage (GPU box): python tools/layer_report.py [model.yaml] [imgsz] [batch] [rows] [eval]
+(`eval` as fifth argument: the eval forward + postprocess instead of the training step)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,7 +22,17 @@ if hasattr(model.model[-1], "restack"):
 batch = synth_batch(B, S, S, 1, dev, nc=model.yaml["nc"])
 
 
+EVAL = len(sys.argv) > 5 and sys.argv[5] == "eval"
+if EVAL:
+    from yolov10_3d_amd.loss import v10_3Dpostprocess, v10postprocess
+    model.eval()
+
+
 def step():
+    if EVAL:
+        with torch.no_grad():
+            y = model(batch["img"])["one2one"][0]
+            return (v10_3Dpostprocess if "3D" in name else v10postprocess)(y.permute(0, 2, 1), 50 if "3D" in name else 300, model.yaml["nc"])
     loss, _ = model(batch)
     loss.backward()
     opt.step(max_norm=10.0)
@@ -38,7 +49,7 @@ res = ops.TIMER.results()
 ops.TIMER = None
 rows = []
 for key, ts in res.items():
-    kind, dt, b, h, w, cin, cout, k, s, g = key
+    kind, dt, b, h, w, cin, cout, k, s, g = key[:10]
     ho, wo = (h + s - 1) // s, (w + s - 1) // s
     fl = 2.0 * b * ho * wo * cout * (cin // g) * k * k
     ms = sum(ts) / N  # per step (all launches of this shape)

@@ -9,94 +9,111 @@
 
 namespace {
 
-// (value desc, index asc) arg-max exchange steps on the VALU: DPP swizzles inside a 16-lane row, gfx950 row swaps across rows - no LDS
-// crossbar (`__shfl_xor` = ds_bpermute: twelve dependent ~100-cycle round trips per winner in the first form of this reduction)
-__device__ __forceinline__ void amax_pick(float& v, int& i, float v2, int i2) {
-  const bool take = v2 > v || (v2 == v && i2 < i);
-  v = take ? v2 : v;
-  i = take ? i2 : i;
-}
-template <int CTRL> __device__ __forceinline__ void amax_dpp(float& v, int& i) {
-  const float v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-  const int i2 = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, false);
-  amax_pick(v, i, v2, i2);
-}
-__device__ __forceinline__ void amax_row16(float& v, int& i) {  // every lane of a 16-lane row ends with the row's best
-  amax_dpp<0xB1>(v, i);   // quad_perm [1,0,3,2]
-  amax_dpp<0x4E>(v, i);   // quad_perm [2,3,0,1]
-  amax_dpp<0x141>(v, i);  // row_half_mirror
-  amax_dpp<0x140>(v, i);  // row_mirror
-}
-__device__ __forceinline__ void amax_wave(float& v, int& i) {  // every lane ends with the wave's best
-  amax_row16(v, i);
-  {
-    auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    auto ri = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
-    float a = __uint_as_float(rv[0]);
-    int ai = (int)ri[0];
-    amax_pick(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
-    v = a; i = ai;
-  }
-  {
-    auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    auto ri = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);
-    float a = __uint_as_float(rv[0]);
-    int ai = (int)ri[0];
-    amax_pick(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
-    v = a; i = ai;
-  }
+// Order-preserving key of a float: larger value <=> larger key (-0 counts as +0).  Inputs are finite or +-inf (a NaN would sort first).
+__device__ __forceinline__ unsigned topk_key(float v) {
+  const unsigned u = __float_as_uint(v + 0.f);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
 
-// K times the block-wide arg-max of (value desc, index asc) over `n` LDS values, earlier winners excluded by overwriting them with -inf.
-// Every thread keeps the best of ITS strided subset in registers; a round is one wave reduction on the VALU (amax_wave), one LDS
-// hand-off between the (<= 16) waves - double-buffered, so ONE barrier per winner; every thread then reads ONE wave's entry and folds
-// the 16 of them inside its DPP row - and a rescan of the winner's subset by its owner thread only.  (First form: a rescan of all n
-// values, shuffles through the LDS crossbar, a serial fold of the waves and two barriers per winner: 2.8 us per winner, 277 us for the
-// postprocess of a batch of 32.)   sv / si: at least 32 entries each.
-__device__ void block_topk(float* vals, int n, int K, int* out_idx, float* out_val, float* sv, int* si) {
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  if (tid < 32) { sv[tid] = -INFINITY; si[tid] = 0x7fffffff; }  // entries of waves that do not exist never win
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int a = tid; a < n; a += nt) {
-    const float v = vals[a];
-    if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
-  }
-  __syncthreads();
-  for (int j = 0; j < K; ++j) {
-    float wv = bv;
-    int wi = bi;
-    amax_wave(wv, wi);
-    float* svj = sv + (j & 1) * 16;
-    int* sij = si + (j & 1) * 16;
-    if (lane == 0) { svj[wave] = wv; sij[wave] = wi; }
+// words of LDS work space block_topk needs for K winners: 256 histogram bins, 32 per-wave sums, 8 control words, K values + K indices
+__host__ __device__ constexpr int topk_ws(int K) { return 296 + 2 * K; }
+
+// The K best of `n` LDS values by (value desc, index asc), written in that order (n >= K; `vals` is left untouched).
+// Radix select instead of K arg-max rounds (first form: one barrier + one wave reduction per winner, 2.9 us each - 148 us for the
+// postprocess of a batch, 78 us for the 50 cells of an 80x80 level): four 8-bit passes over the keys find the key T of the K-th value
+// (LDS histogram of the elements that match the prefix found so far, wave 0 walks the 256 bins from the top); then ONE ordered
+// compaction - every thread owns a contiguous chunk, a block scan of the (> T, == T) counts places all elements above T and the
+// lowest-index `need` elements equal to T - and a rank sort of the K survivors.  ~12 barriers in total, independent of K.
+__device__ void block_topk(const float* vals, int n, int K, int* out_idx, float* out_val, int* ws) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  int* hist = ws;                     // [256]
+  int* wsum = ws + 256;               // [2][16]
+  int* ctl = ws + 288;                // [0] bin, [1] winners still to take inside it
+  float* selv = (float*)(ws + 296);   // [K]
+  int* seli = ws + 296 + K;           // [K]
+  unsigned prefix = 0;
+  int need = K;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const unsigned mask = pass ? 0xffffffffu << (shift + 8) : 0u;
+    for (int i = tid; i < 256; i += nt) hist[i] = 0;
     __syncthreads();
-    float gv = svj[lane & 15];
-    int gi = sij[lane & 15];
-    amax_row16(gv, gi);
-    if (tid == 0) {
-      out_idx[j] = gi < n ? gi : 0;
-      if (out_val) out_val[j] = gv;
+    for (int a = tid; a < n; a += nt) {
+      const unsigned k = topk_key(vals[a]);
+      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
     }
-    if (gi < n && gi % nt == tid) {  // the owner retires the winner and finds the next best of its subset
-      vals[gi] = -INFINITY;          // -inf entries can only be re-selected when fewer than K finite values exist
-      bv = -INFINITY;
-      bi = 0x7fffffff;
-      for (int a = tid; a < n; a += nt) {
-        const float v = vals[a];
-        if (v > bv || (v == bv && a < bi)) { bv = v; bi = a; }
+    __syncthreads();
+    if (wave == 0) {  // lane L owns bins 255 - 4L .. 252 - 4L; the bin where the count from the top reaches `need`
+      const int h0 = hist[255 - 4 * lane], h1 = hist[254 - 4 * lane], h2 = hist[253 - 4 * lane], h3 = hist[252 - 4 * lane];
+      const int s = h0 + h1 + h2 + h3;
+      int inc = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+      }
+      int c = inc - s;  // elements in the bins above this lane's
+      if (c < need && need <= inc) {
+        int bin = 255 - 4 * lane;
+        if (need > c + h0) { c += h0; --bin; if (need > c + h1) { c += h1; --bin; if (need > c + h2) { c += h2; --bin; } } }
+        ctl[0] = bin;
+        ctl[1] = need - c;
       }
     }
+    __syncthreads();
+    prefix |= (unsigned)ctl[0] << shift;
+    need = ctl[1];
+  }
+  // prefix = key of the K-th value; `need` of the elements with that key are winners (the lowest indices), all elements above it are
+  const unsigned T = prefix;
+  const int above = K - need;
+  const int chunk = ((n + nt - 1) / nt) | 1;  // odd: consecutive threads start on different LDS banks
+  const int a0 = min(n, tid * chunk), a1 = min(n, a0 + chunk);
+  int gt = 0, eq = 0;
+  for (int a = a0; a < a1; ++a) {
+    const unsigned k = topk_key(vals[a]);
+    gt += k > T;
+    eq += k == T;
+  }
+  int ig = gt, ie = eq;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(ig, d), u = __shfl_up(ie, d);
+    if (lane >= d) { ig += t; ie += u; }
+  }
+  if (lane == 63) { wsum[wave] = ig; wsum[16 + wave] = ie; }
+  __syncthreads();
+  int pg = ig - gt, pe = ie - eq;
+  for (int w = 0; w < wave; ++w) { pg += wsum[w]; pe += wsum[16 + w]; }
+  for (int a = a0; a < a1; ++a) {
+    const float v = vals[a];
+    const unsigned k = topk_key(v);
+    if (k > T) { selv[pg] = v; seli[pg] = a; ++pg; }
+    else if (k == T) {
+      if (pe < need) { selv[above + pe] = v; seli[above + pe] = a; }
+      ++pe;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < K; j += nt) {
+    const float v = selv[j];
+    const int i = seli[j];
+    int r = 0;
+    for (int q = 0; q < K; ++q) {
+      const float v2 = selv[q];
+      r += (v2 > v) || (v2 == v && seli[q] < i);
+    }
+    out_idx[r] = i;
+    if (out_val) out_val[r] = v;
   }
   __syncthreads();  // out_idx / out_val (often LDS) are complete for every thread
 }
 
 template <typename T>
 __global__ __launch_bounds__(1024) void topk_cells_kernel(const T* __restrict__ cls, long psw, int HW, int nc, int K, int* __restrict__ out) {
-  extern __shared__ float sm[];  // [HW] + reduction scratch
+  extern __shared__ float sm[];  // [HW] + selection work space
   float* vals = sm;
-  float* sv = sm + HW;
-  int* si = (int*)(sv + 256);
+  int* ws = (int*)(sm + HW);
   const int b = blockIdx.x;
   for (int a = threadIdx.x; a < HW; a += blockDim.x) {
     const T* p = cls + ((long)b * HW + a) * psw;
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(1024) void topk_cells_kernel(const T* __restrict__ 
     vals[a] = m;
   }
   __syncthreads();
-  block_topk(vals, HW, K, out + (long)b * K, nullptr, sv, si);
+  block_topk(vals, HW, K, out + (long)b * K, nullptr, ws);
 }
 
 // patches[(b*K + j)][py][px][c] = x[b][row - pad + py][col - pad + px][c]  (zero outside the map)
@@ -384,9 +401,8 @@ __global__ __launch_bounds__(1024) void postprocess_seg_kernel(const float* __re
                                                               float* __restrict__ scratch) {
   extern __shared__ float sm[];
   float* vals = sm;            // [seglen]
-  float* sv = sm + seglen;     // [256]
-  int* si = (int*)(sv + 256);  // [256]
-  int* top = si + 256;         // [K]
+  int* ws = (int*)(sm + seglen);  // [topk_ws(K)]
+  int* top = ws + topk_ws(K);  // [K]
   float* tv = (float*)(top + K);  // [K]
   const int seg = blockIdx.x, nseg = gridDim.x, b = blockIdx.y;
   const float* yb = y + (long)b * C * A;
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(1024) void postprocess_seg_kernel(const float* __re
   }
   __syncthreads();
   const int kk = min(K, n);
-  block_topk(vals, n, kk, top, tv, sv, si);
+  block_topk(vals, n, kk, top, tv, ws);
   float* cv = scratch + ((long)b * nseg + seg) * K;
   int* ci = (int*)(scratch + (long)gridDim.y * nseg * K) + ((long)b * nseg + seg) * K;
   for (int i = threadIdx.x; i < K; i += blockDim.x) {
@@ -417,9 +433,8 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(const float* __restri
   // K best anchors of each of `nseg` anchor segments: scratch holds their values [B][nseg*K] and anchor indices [B][nseg*K]
   const int ncand = scratch ? nseg * K : A;
   float* vals = sm;           // [ncand]
-  float* sv = sm + ncand;     // [256]
-  int* si = (int*)(sv + 256);   // [256]
-  int* top = si + 256;          // [K]
+  int* ws = (int*)(sm + ncand);  // [topk_ws(K)]
+  int* top = ws + topk_ws(K);   // [K]
   float* sc2 = (float*)(top + K);  // [K*nc]
   int* top2 = (int*)(sc2 + K * nc);  // [K]
   float* val2 = (float*)(top2 + K);  // [K]
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(const float* __restri
     }
   }
   __syncthreads();
-  block_topk(vals, ncand, K, top, nullptr, sv, si);
+  block_topk(vals, ncand, K, top, nullptr, ws);
   if (scratch) {  // candidate position -> anchor index (positions are ordered by segment, then by rank: ties keep the lowest anchor first)
     const int* ci = (const int*)(scratch + (long)gridDim.x * ncand) + (long)b * ncand;
     for (int i = threadIdx.x; i < K; i += blockDim.x) top[i] = ci[top[i]];
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(const float* __restri
   }
   for (int i = threadIdx.x; i < K * nc; i += blockDim.x) sc2[i] = yb[(long)(s0 + i % nc) * A + top[i / nc]];
   __syncthreads();
-  block_topk(sc2, K * nc, K, top2, val2, sv, si);
+  block_topk(sc2, K * nc, K, top2, val2, ws);
   for (int i = threadIdx.x; i < K; i += blockDim.x) {
     scores[(long)b * K + i] = val2[i];
     labels[(long)b * K + i] = top2[i] % nc;
@@ -532,7 +547,7 @@ extern "C" {
 int y3d_topk_cells(int dtype, const void* cls, int64_t psw, int B, int HW, int nc, int K, int* out_idx, void* stream) {
   Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "topk_cells: bad dtype");
   Y3D_CHECK(K >= 1 && K <= HW, "topk_cells: need 1 <= K <= H*W (K=%d, H*W=%d)", K, HW);
-  size_t sm = (size_t)(HW + 512) * 4;
+  size_t sm = (size_t)(HW + topk_ws(K)) * 4;
   Y3D_CHECK(sm <= 160 * 1024, "topk_cells: map of %d cells does not fit LDS", HW);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == Y3D_BF16) {
@@ -607,7 +622,7 @@ int y3d_head2d_decode(int dtype, int nl, const void* const* maps, const int* H, 
 }
 
 int y3d_v10_postprocess_scratch_floats(int B, int A, int nc, int max_det) {
-  return (size_t)(A + 512 + max_det * (nc + 3)) * 4 <= 160 * 1024 ? 0 : B * A;
+  return (size_t)(A + topk_ws(max_det) + max_det * (nc + 3)) * 4 <= 160 * 1024 ? 0 : B * A;
 }
 
 int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det, int boxes_first, float* reg, float* scores,
@@ -622,12 +637,12 @@ int y3d_v10_postprocess(const float* y, int B, int C, int A, int nc, int max_det
     nseg = 16;
     while (nseg > 1 && (long)nseg * max_det * 2 > A) nseg >>= 1;
     seglen = cdiv(A, nseg);
-    Y3D_CHECK((long)nseg * max_det * 2 <= A && (size_t)(seglen + 512 + 2 * max_det) * 4 <= 160 * 1024, "v10_postprocess: %d anchors with max_det %d", A, max_det);
-    size_t sm1 = (size_t)(seglen + 512 + 2 * max_det) * 4;
+    Y3D_CHECK((long)nseg * max_det * 2 <= A && (size_t)(seglen + topk_ws(max_det) + 2 * max_det) * 4 <= 160 * 1024, "v10_postprocess: %d anchors with max_det %d", A, max_det);
+    size_t sm1 = (size_t)(seglen + topk_ws(max_det) + 2 * max_det) * 4;
     (void)hipFuncSetAttribute((const void*)postprocess_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(postprocess_seg_kernel, dim3(nseg, B), dim3(1024), sm1, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, seglen, scratch);
   }
-  size_t sm = (size_t)((fits ? A : nseg * max_det) + 512 + max_det * (nc + 3)) * 4;
+  size_t sm = (size_t)((fits ? A : nseg * max_det) + topk_ws(max_det) + max_det * (nc + 3)) * 4;
   Y3D_CHECK(sm <= 160 * 1024, "v10_postprocess: max_det * nc = %d does not fit LDS", max_det * nc);
   (void)hipFuncSetAttribute((const void*)postprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3((fits ? A : nseg * max_det) >= 2048 ? 1024 : 256), sm, (hipStream_t)stream, y, A, C, nc, max_det, boxes_first, reg, scores, (long*)labels, scratch,
