@@ -175,6 +175,20 @@ int y3d_stem_im2col(int dtype, const float* x_nchw, void* out, int B, int H, int
 /* the same from the dataset's uint8 image (NCHW: hwc = 0, NHWC as decoded: hwc = 1) with the /255 of data/datasets/kitti.py:204-205
  * (models/yolo/detect/train.py:59 for the 2D trainer) done on the device: 1 byte per sample crosses PCIe / HBM instead of 4 */
 int y3d_stem_im2col_u8(int dtype, const uint8_t* x, int hwc, void* out, int B, int H, int W, int Ho, int Wo, void* stream);
+/* the eval stem in one pass - Conv(3, Cout, 3, 2) with running-statistics BatchNorm folded into (scale, shift) and SiLU (act != 0),
+ * nn/modules/conv.py:120-122 on yaml row 0: x = (B, 3, H, W) fp32 (in_mode 0), (B, 3, H, W) uint8 (1) or (B, H, W, 3) uint8 (2; uint8
+ * samples are divided by 255 as data/datasets/kitti.py:204-205); wcol = [Cout][32] fp32 with column (r*3+q)*3+ci of the 3x3 window
+ * (27..31 zero); y = bf16 (B, Ho, Wo) pixels x Cout channels (16, 32, 48, 64 or 80), pixel pitch ysw elements.  bf16 arithmetic as
+ * y3d_stem_im2col + y3d_conv2d_fwd_affine, without the column tensor. */
+int y3d_stem_conv_eval(const void* x, int in_mode, const float* wcol, const float* scale, const float* shift, int act, void* y, int64_t ysw,
+                       int B, int H, int W, int Cout, void* stream);
+/* the training stem in one pass: the same gather + MFMA writing the raw conv output y (bf16, before BatchNorm), the column tensor
+ * xcol = [B*Ho*Wo][32] bf16 that y3d_stem_im2col would have produced (operand of the weight gradient) and BatchNorm partials
+ * part[rows][Cout][2] (sum, sum of squares of the stored values; rows = y3d_stem_conv_train_rows) for y3d_bn_finalize -
+ * replaces y3d_stem_im2col + y3d_conv2d_fwd (K = 32), which wrote the column tensor and read it back */
+int y3d_stem_conv_train_rows(int B, int H, int W);
+int y3d_stem_conv_train(const void* x, int in_mode, const float* wcol, void* y, int64_t ysw, void* xcol, float* part, int B, int H, int W,
+                        int Cout, void* stream);
 int y3d_nhwc_to_nchw(int dtype, const void* x_nhwc, int64_t xsw, float* y_nchw, int B, int C, int H, int W, void* stream);
 /* head final nn.Conv2d(c, out, 1) with bias, out <= 24 — head.py:637 (3D branches: nc,2,2,2,3,24,1,1) */
 int y3d_proj_fwd(int dtype, const void* x, int64_t xsw, const float* w, const float* bias, void* y, int64_t ysw, int64_t P,

@@ -3,6 +3,8 @@ and against the CPU oracle restatement on fresh seeded inputs.
 
 fp32 mode (exact-f32 MFMA) is held to 1e-3 relative on every output (north_star tolerance);
 bf16 mode (the performance mode) is held to a documented looser bound."""
+import copy
+
 import pytest
 import torch
 
@@ -208,6 +210,83 @@ def test_head3d_eval_vs_reference_golden(tag):
     for a, b in zip(maps2, g["maps"]):
         check(a, b, 1e-3, "eval map, reference candidates")
     check(y2, g["y"], 1e-3, "eval output, reference candidates")
+
+
+@pytest.mark.parametrize("cout", [16, 32, 48, 64, 80])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 67, 101), (1, 258, 130)])
+def test_fused_eval_stem_matches_two_step_form_and_fp32_reference(cout, B, H, W):
+    """csrc/stem_fused.hip (eval stem in one pass: window gather -> one 16x16x32 MFMA -> folded BatchNorm + SiLU) against (a) the
+    two-step form the training path uses (y3d_stem_im2col + dense conv, `ops.STEM_FUSED = False`) - same bf16 operands, so equal up to
+    the rounding of a different fp32 summation order - and (b) torch's fp32 conv + eval BatchNorm + SiLU within the bf16 bound; fp32
+    NCHW, uint8 NCHW and uint8 NHWC (channels-last) images, odd sizes, every stem width of the model family (N 16 ... X 80)"""
+    from yolov10_3d_amd import ops
+    import torch.nn.functional as F
+    y3d.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(cout + H)
+    m = M.Conv(3, cout, 3, 2).to(DEV).eval()
+    with torch.no_grad():
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.uniform_(-0.5, 0.5)
+        m.bn.running_mean.uniform_(-0.2, 0.2)
+        m.bn.running_var.uniform_(0.5, 1.5)
+    u8 = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device=DEV)
+    imgs = {"f32": torch.rand(B, 3, H, W, device=DEV), "u8": u8, "u8_hwc": u8.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)}
+    for name, img in imgs.items():
+        res = {}
+        for fused in (True, False):
+            ops.STEM_FUSED = fused
+            try:
+                with torch.no_grad():
+                    res[fused] = m(img).float()
+            finally:
+                ops.STEM_FUSED = True
+            ops.bump_param_epoch()  # drop the eval caches between the two forms
+        xf = img.float() / 255 if img.dtype == torch.uint8 else img
+        with torch.no_grad():
+            ref = F.silu(F.batch_norm(F.conv2d(xf, m.conv.weight, None, 2, 1), m.bn.running_mean, m.bn.running_var, m.bn.weight, m.bn.bias, False, 0.0, m.bn.eps))
+        assert res[True].shape == ref.shape
+        check(res[True], res[False], 8e-3, f"{name}: fused vs two-step")     # one bf16 ulp of the largest output
+        check(res[True], ref, 2e-2, f"{name}: fused vs fp32 reference")
+        frac = (res[True] == res[False]).float().mean().item()
+        assert frac > 0.97, f"{name}: only {frac:.3f} of the outputs are bit-identical to the two-step form"
+
+
+@pytest.mark.parametrize("cout", [16, 32, 80])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 67, 101), (2, 258, 130)])
+def test_fused_train_stem_matches_two_step_form(cout, B, H, W):
+    """training stem: one pass (raw conv output + BatchNorm partials + column tensor) against im2col + dense conv on the same operands:
+    activations, running statistics, weight / BatchNorm gradients (the backward is shared: it reads the column tensor either form wrote)"""
+    from yolov10_3d_amd import ops
+    y3d.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(cout + W)
+    m0 = M.Conv(3, cout, 3, 2).to(DEV).train()
+    with torch.no_grad():
+        m0.bn.weight.uniform_(0.5, 1.5)
+        m0.bn.bias.uniform_(-0.5, 0.5)
+    img = torch.rand(B, 3, H, W, device=DEV)
+    u8 = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=DEV).permute(0, 3, 1, 2)
+    for x in (img, u8):
+        res = {}
+        for fused in (True, False):
+            m = copy.deepcopy(m0)
+            ops.STEM_FUSED = fused
+            try:
+                z = m(x)
+                r = torch.linspace(-1, 1, z.numel(), device=DEV).view(z.shape)
+                (z.float() * r).sum().backward()
+            finally:
+                ops.STEM_FUSED = True
+            res[fused] = (z.detach().float(), m.conv.weight.grad.clone(), m.bn.weight.grad.clone(), m.bn.bias.grad.clone(),
+                          m.bn.running_mean.clone(), m.bn.running_var.clone())
+        names = ("z", "dW", "dgamma", "dbeta", "running_mean", "running_var")
+        for n, a, b in zip(names, res[True], res[False]):
+            # a raw output that rounds to the other bf16 neighbour (different fp32 summation order) moves z by a few bf16 ulps through BatchNorm
+            check(a, b, 3e-2 if n in ("z", "dW", "dgamma", "dbeta") else 1e-4, f"{n}: fused vs two-step")
+        xf = x.float() / 255 if x.dtype == torch.uint8 else x
+        mr = copy.deepcopy(m0).float()
+        ref = torch.nn.functional.silu(mr.bn(torch.nn.functional.conv2d(xf, mr.conv.weight, None, 2, 1)))
+        check(res[True][0], ref, 3e-2, "z vs torch fp32")
+        check(res[True][4], mr.bn.running_mean, 2e-2, "running_mean vs torch fp32", floor=1e-2)
 
 
 def _opt_head(meta, nl=2):

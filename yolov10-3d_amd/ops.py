@@ -378,6 +378,7 @@ def set_weight_quant(mode):
 def weight_quant():
     return WEIGHT_QUANT
 PROJ_BN_MFMA = not os.environ.get("Y3D_NO_PROJ_BN_MFMA")  # A/B switch: BatchNorm backward of the second head layer recomputing dz on MFMA
+STEM_FUSED = not os.environ.get("Y3D_NO_STEM_FUSED")  # A/B switch: eval stem as im2col + dense conv (the training form) instead of one pass
 PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv packing launches instead of the registry
 
 
@@ -425,7 +426,7 @@ def _timed(key, launch):
 
 
 def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, training, eps, momentum, cache=None, bn_apply=True, pack_cache=True,
-                 ver=None, quant=True):
+                 ver=None, quant=True, pre_conv=None):
     """conv -> BN statistics -> BN apply + SiLU (+res).  Returns (z, saved) with everything the backward needs.
     ver = (weights token, all-tensors token) of a stacked view (StackedConvs), None for tensors that carry their own counters."""
     L = lib()
@@ -447,13 +448,6 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     if Cin == 3 and k == 3 and s == 2 and p == 1 and g == 1 and not x.requires_grad:
         # the stem: im2col the image once (27 window values + 5 zeros per output pixel) and run a dense 1x1 conv with K = 32;
         # as a 9-tap conv over an 8-channel-padded image the MFMA tiles were 86 % padding.  dW is mapped back in _cba_backward.
-        xcol = nhwc_empty(B, 32, Ho, Wo, dtype, dev)
-        if x.dtype == torch.uint8:  # the dataset's bytes: /255 happens in the kernel (NCHW, or NHWC when the tensor is channels-last)
-            hwc = int(not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous())
-            xs = x if (hwc or x.is_contiguous()) else x.contiguous()
-            L.stem_im2col_u8(dt, xs.data_ptr(), hwc, xcol.data_ptr(), B, H, W, Ho, Wo, st)
-        else:
-            L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
         wkey = ("stemcol", PARAM_EPOCH, w32.data_ptr(), ver[0] if ver is not None else w32._version)
         wcol = cache.get(wkey) if (cache is not None and not training) else None
         if wcol is None:
@@ -463,6 +457,43 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                 for old in [q for q in cache if q[1] != PARAM_EPOCH]:
                     del cache[old]
                 cache[wkey] = wcol
+        if (not training and not res_mode and dtype == torch.bfloat16 and Cout % 16 == 0 and 16 <= Cout <= 80 and STEM_FUSED
+                and x.dtype in (torch.uint8, torch.float32)):
+            # eval: gather + MFMA + folded BatchNorm + SiLU in one pass over the image (csrc/stem_fused.hip); no column tensor
+            _, ss = _eval_consts(cache, "dense", wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, ver, dtype, 1, 1, 32, 32, Cout, eps)
+            if x.dtype == torch.uint8:
+                hwc = int(not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous())
+                xs, mode = (x if (hwc or x.is_contiguous()) else x.contiguous()), 1 + hwc
+            else:
+                xs, mode = x.contiguous(), 0
+            ye = out_tensor(B, Cout, Ho, Wo, dtype, dev)
+            _timed(("conv_eval", dt, B, H, W, 3, Cout, 3, 2, 1, 1),
+                   lambda: L.stem_conv_eval(xs.data_ptr(), mode, wcol.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), int(act), ye.data_ptr(), ye.stride(3),
+                                            B, H, W, Cout, st))
+            return ye, None, None
+        xcol = nhwc_empty(B, 32, Ho, Wo, dtype, dev)
+        if training and dtype == torch.bfloat16 and Cout % 16 == 0 and 16 <= Cout <= 80 and STEM_FUSED and x.dtype in (torch.uint8, torch.float32):
+            # training: the same one-pass kernel writes the raw conv output, the BatchNorm partials and - its own B operand - the column
+            # tensor the weight gradient reads; the two-step form wrote the column tensor and read it back (im2col 167 us + conv 146 us)
+            if x.dtype == torch.uint8:
+                hwc = int(not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous())
+                xs, mode = (x if (hwc or x.is_contiguous()) else x.contiguous()), 1 + hwc
+            else:
+                xs, mode = x.contiguous(), 0
+            rows = L.stem_conv_train_rows(B, H, W)
+            ypre = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+            part = _f32(rows * Cout * 2, dev)
+            _timed(("conv_fwd", dt, B, H, W, 3, Cout, 3, 2, 1),
+                   lambda: L.stem_conv_train(xs.data_ptr(), mode, wcol.data_ptr(), ypre.data_ptr(), ypre.stride(3), xcol.data_ptr(), part.data_ptr(), B, H, W, Cout, st))
+            z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache,
+                                         pack_cache=False, quant=False, pre_conv=(ypre, part, rows))
+            return z, (cfg + ("stem",) if cfg is not None else None), saved
+        if x.dtype == torch.uint8:  # the dataset's bytes: /255 happens in the kernel (NCHW, or NHWC when the tensor is channels-last)
+            hwc = int(not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous())
+            xs = x if (hwc or x.is_contiguous()) else x.contiguous()
+            L.stem_im2col_u8(dt, xs.data_ptr(), hwc, xcol.data_ptr(), B, H, W, Ho, Wo, st)
+        else:
+            L.stem_im2col(dt, x.float().contiguous().data_ptr(), xcol.data_ptr(), B, H, W, Ho, Wo, st)
         z, cfg, saved = _cba_forward(xcol, wcol.view(Cout, 32, 1, 1), g32, b32, rm, rv, 1, 1, 0, 1, act, res, res_mode, training, eps, momentum, cache,
                                      pack_cache=False, quant=False)  # wcol is built from the already quantised stem weight
         return z, (cfg + ("stem",) if cfg is not None else None), saved
@@ -494,6 +525,8 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
             wp, ss_eval = _eval_consts(cache, "dw", w32, g32, b32, rm, rv, ver, dtype, k, g, 1, 1, Cout, eps)
         L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
                        part.data_ptr() if training else None, st)
+    elif pre_conv is not None:  # the caller has run the conv (fused training stem): pre-BN tensor + BatchNorm partial rows
+        y, part, nblk = pre_conv
     else:
         nblk = L.conv2d_stat_rows(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)
         if training:
