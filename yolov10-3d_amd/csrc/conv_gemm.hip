@@ -720,18 +720,26 @@ int launch_conv_mode(ConvP p, hipStream_t st) {
   dim3 block(256);
   const unsigned ny = MODE == 2 ? 4 : 1;  // parity classes
   p.ntx = MODE == 2 ? cdiv((long)p.B * ((p.Hq + 1) / 2) * ((p.Wq + 1) / 2), 128) : cdiv(p.M, 128);
-  if (p.Cn > 64) {
-    p.nty = cdiv(p.Cn, 128);
+  // channel tile: 128 wide, unless that leaves most of the chip idle - the stride-32 level (20x20, B = 32: 100 pixel tiles) ran a
+  // 4 608-deep reduction on 100 workgroups (512 -> 128 3x3: 97 us, 155 TFLOP/s); narrower tiles put 2-4x as many workgroups to work
+  // on the same reduction depth
+  static const char* nosplit = getenv("Y3D_GEMM_WIDE_ONLY");  // A/B knob
+  const long t128 = (long)p.ntx * cdiv(p.Cn, 128) * ny * p.G;
+  int bc = p.Cn > 64 ? 128 : (p.Cn > 32 ? 64 : 32);
+  if (!nosplit && p.Cn % 32 == 0) {
+    if (bc == 128 && t128 < 192) bc = 64;
+    if (bc == 64 && (long)p.ntx * cdiv(p.Cn, 64) * ny * p.G < 192 && p.Cn > 32) bc = 32;
+  }
+  p.nty = cdiv(p.Cn, bc);
+  if (bc == 128) {
     size_t sm = 2 * (128 + 128) * 128;
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2, MODE>), dim3(p.ntx * p.nty, ny, p.G), block, sm, st, p);
-  } else if (p.Cn > 32) {
-    p.nty = 1;
+  } else if (bc == 64) {
     size_t sm = 2 * (128 + 64) * 128;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 4, 1, MODE>), dim3(p.ntx, ny, p.G), block, sm, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 4, 1, MODE>), dim3(p.ntx * p.nty, ny, p.G), block, sm, st, p);
   } else {
-    p.nty = 1;
     size_t sm = 2 * (128 + 32) * 128;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1, MODE>), dim3(p.ntx, ny, p.G), block, sm, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1, MODE>), dim3(p.ntx * p.nty, ny, p.G), block, sm, st, p);
   }
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
