@@ -821,7 +821,9 @@ int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int
     static int target = 0;
     if (!target) { const char* e = getenv("Y3D_WG1_TARGET"); target = e ? atoi(e) : 256; }
     const long tiles = (long)cdiv(Cin, Cin <= 64 ? 64 : 128) * cdiv(Cout, Cout <= 64 ? 64 : 128);
-    long want = cdiv(target, tiles), maxs = cdiv((long)B * H * W, 4 * 64);
+    // rounded down, as y3d_wgrad_tile_splits: 15 tiles (640 -> 320, X widths) x 18 splits = 270 workgroups = a second round for 14 of them
+    static const bool ceil_splits = getenv("Y3D_WG_CEIL") != nullptr;  // A/B knob: the previous rounding
+    long want = ceil_splits ? cdiv(target, tiles) : target / tiles, maxs = cdiv((long)B * H * W, 4 * 64);
     if (want > maxs) want = maxs;
     return (int)(want < 1 ? 1 : want);
   }
