@@ -587,8 +587,8 @@ class v10Detect3d(nn.Module):
                 w2, g2, b2, rm2, rv2 = s2.tensors()
                 z2 = ops.conv_bn_act_eval(z1, w2[lo:hi], g2[lo:hi], b2[lo:hi], rm2[lo:hi], rv2[lo:hi], self.kernel_size_2, 1, 0, 7,
                                           c0.has_act, c0.eps, s2.__dict__.setdefault("_eval_cache", {}), ver=s2.ver)
-                reg = ops.HeadProjSlicesFn.apply(z2, [j * mid for j in range(7)], [mid] * 7, 7, *[heads[j][i][2].weight for j in range(1, 8)],
-                                                 *[heads[j][i][2].bias for j in range(1, 8)])[:, :, 0, 0]
+                reg = ops.proj_slices_eval(z2, [j * mid for j in range(7)], mid, [heads[j][i][2].weight for j in range(1, 8)],
+                                           [heads[j][i][2].bias for j in range(1, 8)])[:, :, 0, 0]
             else:
                 feats = []
                 for j in range(1, 8):

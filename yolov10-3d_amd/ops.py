@@ -1005,6 +1005,36 @@ class HeadProjFn(torch.autograd.Function):
         return (None, *dxs, *dws, *dbs)
 
 
+_IDENT = {}  # (channels, device) -> (ones, zeros): the identity BatchNorm of the eval projection
+
+
+def proj_slices_eval(x, offsets, cin, ws, bs):
+    """eval form of HeadProjSlicesFn (no graph): branch j projects channels [offsets[j], offsets[j] + cin) of the ACTIVATED features x with
+    its 1x1 conv + bias (head.py:637), all branches in one launch.  bf16 with 64 / 128 channels per branch: the matrix-core kernel of
+    the training head (proj_bn_mfma.hip) with an identity BatchNorm (scale 1, shift 0, no activation) - the VALU form
+    (y3d_proj_group_fwd) took 42 us per level for the 1 600 candidate pixels of a batch of 32 (128-long serial dot products)."""
+    import ctypes
+    n = len(ws)
+    dtype = _COMPUTE_DTYPE
+    if not (dtype == torch.bfloat16 and cin in (64, 128) and PROJ_BN_MFMA and n <= 16):
+        return HeadProjSlicesFn.apply(x, offsets, [cin] * n, n, *ws, *bs)
+    L, st = lib(), stream()
+    x = to_nhwc(x, dtype, dense=True)
+    B, Ct, H, W = x.shape
+    couts = [w.shape[0] for w in ws]
+    tot = sum(couts)
+    out = nhwc_empty(B, tot, H, W, dtype, x.device)
+    w32 = [w.detach().float().contiguous() for w in ws]
+    b32 = [b.detach().float().contiguous() for b in bs]
+    ident = _IDENT.get((Ct, x.device))
+    if ident is None:
+        ident = _IDENT[(Ct, x.device)] = (torch.ones(Ct, dtype=torch.float32, device=x.device), torch.zeros(Ct, dtype=torch.float32, device=x.device))
+    PV, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    L.proj_group_fwd_bn_mfma(n, cin, x.data_ptr(), x.stride(3), IA(*offsets), PV(*[t.data_ptr() for t in w32]), PV(*[t.data_ptr() for t in b32]), IA(*couts),
+                             ident[0].data_ptr(), ident[1].data_ptr(), 0, out.data_ptr(), tot, B * H * W, st)
+    return out
+
+
 class HeadProjSlicesFn(torch.autograd.Function):
     """Same projections as HeadProjFn, but every branch reads a channel slice [off_j, off_j+cin) of ONE stacked feature
     tensor, all branches of a level run as ONE launch per direction (proj_group.hip) and the backward writes each branch's
