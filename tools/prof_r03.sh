@@ -22,6 +22,9 @@ python3 bench.py --model yolov10m_3D.yaml --no-cpu-baseline --train-graph --infe
 echo configs done
 python3 tools/layer_report.py yolov10s_3D.yaml 640 32 > gpurun_out/${T}_layer_report.txt 2>&1
 python3 tools/layer_report.py yolov10m_3D.yaml 640 32 > gpurun_out/${T}_layer_report_m3d.txt 2>&1
-python3 tools/cu_contention.py 8 16 32 64 > gpurun_out/${T}_cu_contention.txt 2>&1
+python3 tools/layer_report.py yolov10x_3D.yaml 640 16 > gpurun_out/${T}_layer_report_x3d.txt 2>&1
+python3 tools/layer_report.py yolov10l.yaml 1280 8 > gpurun_out/${T}_layer_report_l2d1280.txt 2>&1
+python3 tools/layer_report.py yolov10s_3D.yaml 640 32 400 eval > gpurun_out/${T}_layer_report_eval.txt 2>&1
+echo layer reports done
 python3 -m pytest tests/test_hip_bench_path.py -m gpu -q -s -k autocast 2>&1 | grep "yardstick" > gpurun_out/${T}_bf16_yardstick.txt
 tail -1 gpurun_out/${T}_bench_default.log | cut -c1-600

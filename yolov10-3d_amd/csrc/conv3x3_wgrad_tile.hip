@@ -276,7 +276,9 @@ int launch_wg(const WG3P& p, int nsplit, hipStream_t st) {
 // tile height of the resident wgrad kernel for this geometry (bf16 only), 0 -> generic split-K kernel
 int y3d_wgrad_tile_height(int dtype, int H, int W, int Cg, int Cn, int kh, int kw, int stride, int pad) {
   if (dtype != Y3D_BF16 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return 0;
-  if (Cg % 32 != 0 || Cg < 64 || Cn % 8 != 0 || W < 8) return 0;  // 96 / 160 / ... channels: the last 64-channel slab is half empty
+  // 96 / 160 / ... channels: the last 64-channel slab is half empty; 80 (X widths): a quarter full - 62 % useful MFMAs, against
+  // 266 TFLOP/s for the generic split-K kernel on 80 -> 80 at 160x160 (the DMA zero-fills per 8-channel chunk: `ci0 + h_c < Cg`)
+  if (Cg % 16 != 0 || Cg < 64 || Cn % 8 != 0 || W < 8) return 0;
   if (H % 8 == 0) return 8;
   if (H % 4 == 0) return 4;
   return 0;
