@@ -161,8 +161,11 @@ def main(argv=None):
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--phases", action="store_true", help="per-phase device times (backward / all-reduce / optimizer) in the JSON line (default for N > 1)")
     ap.add_argument("--no-phases", action="store_true", help="N > 1: no per-phase events")
-    ap.add_argument("--train-graph", action="store_true",
-                    help="also time the training step replayed from ONE hipGraph (graph.GraphedTrainStep; 1 GPU): `train_images_per_sec_graph`")
+    ap.add_argument("--train-graph", action="store_true", help="(default at N = 1; kept for old command lines)")
+    ap.add_argument("--no-train-graph", action="store_true",
+                    help="N = 1: do not ALSO time the training step replayed from one hipGraph (graph.GraphedTrainStep).  By default both the "
+                         "launch-by-launch loop and the replay are timed over --steps steps each; `value` is the faster of the two (`train_mode` "
+                         "says which: the eager loop is bound by the host on a slow CPU, the replay never is), both rates are in the line")
     ap.add_argument("--infer-mode", default="graph", choices=["graph", "eager"],
                     help="inference leg: replay the eval forward + postprocess from one captured hipGraph per batch (default), or launch eagerly")
     args = ap.parse_args(argv)
@@ -287,7 +290,7 @@ def main(argv=None):
     train_ips = world * B * args.steps / dt_s
 
     train_graph_ips = None
-    if args.train_graph and world == 1 and reducer is None:
+    if not args.no_train_graph and world == 1 and reducer is None:
         # the same step - forward, loss, backward, clip, SGD - replayed from one captured hipGraph, EMA eagerly behind it; the batches
         # rotate through the graph's static buffers
         try:
@@ -407,14 +410,18 @@ def main(argv=None):
             log("cpu baseline (oracle restatement on the host cores) ...")
             cpu = cpu_baseline(args.model, S, seed=1)
             log(f"cpu baseline: {cpu['value']:.3f} images/s on {cpu['cores']} cores")
+        # the step launched kernel by kernel and the SAME step replayed from one hipGraph were both timed over --steps steps:
+        # the headline is the faster one (the roofline launch and the phases are always measured in the eager loop)
+        best_ips, train_mode = (train_graph_ips, "hipgraph") if (train_graph_ips and train_graph_ips > train_ips) else (train_ips, "eager")
         out = {
-            "metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": "train_images_per_sec", "value": round(best_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * world * B / best_ips, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model}{' (3D head)' if is3d else ' (2D head)'}, {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' MFMA on fp8 e4m3-VALUED conv weights (weight-format emulation: no fp8 MFMA instruction runs, no speed claim)'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": args.backend if dist.is_initialized() else None,
             "steps_skipped_nonfinite": int(opt.last_norm[4]) if opt.last_norm is not None else None,
+            "train_mode": train_mode, "train_images_per_sec_eager": round(train_ips, 2),
             "train_images_per_sec_graph": round(train_graph_ips, 2) if train_graph_ips else None,
             "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None, "infer_mode": infer_mode if infer_ips else None,
             "infer_images_per_sec_eager": round(infer_eager_ips, 2) if infer_eager_ips else None, "roofline_infer": roof_infer,

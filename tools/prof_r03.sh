@@ -6,7 +6,7 @@ O=$R/gpurun_out
 T=r03
 python3 $R/bench.py > $O/${T}_bench_default.log 2>&1
 echo bench done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -o run -- python3 $R/bench.py --steps 4 --warmup 1 --infer-steps 0 --no-cpu-baseline > $O/${T}_bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -o run -- python3 $R/bench.py --steps 4 --warmup 1 --infer-steps 0 --no-cpu-baseline --no-train-graph > $O/${T}_bench_under_rocprof.log 2>&1
 python3 $R/tools/prof_summary.py $O/${T}_prof 5 70 > $O/${T}_bench_kernel_stats_summary.txt
 cp $(find $O/${T}_prof -name "*kernel_stats.csv" | head -1) $O/${T}_bench_kernel_stats.csv
 echo stats done
@@ -17,8 +17,7 @@ cd $R
 python3 bench.py --model yolov10m_3D.yaml --no-cpu-baseline > gpurun_out/${T}_bench_m3d.json 2> gpurun_out/${T}_bench_m3d.log
 python3 bench.py --model yolov10x_3D.yaml --weights fp8 --batch 16 --no-cpu-baseline > gpurun_out/${T}_bench_x3d_fp8.json 2> gpurun_out/${T}_bench_x3d_fp8.log
 python3 bench.py --model yolov10l.yaml --imgsz 1280 --batch 8 --no-cpu-baseline > gpurun_out/${T}_bench_l2d_1280.json 2> gpurun_out/${T}_bench_l2d_1280.log
-python3 bench.py --model yolov10n_3D.yaml --no-cpu-baseline --train-graph > gpurun_out/${T}_bench_n3d_graph.json 2> gpurun_out/${T}_bench_n3d_graph.log
-python3 bench.py --model yolov10m_3D.yaml --no-cpu-baseline --train-graph --infer-steps 0 > gpurun_out/${T}_bench_m3d_graph.json 2> gpurun_out/${T}_bench_m3d_graph.log
+python3 bench.py --model yolov10n_3D.yaml --no-cpu-baseline > gpurun_out/${T}_bench_n3d.json 2> gpurun_out/${T}_bench_n3d.log
 echo configs done
 python3 tools/layer_report.py yolov10s_3D.yaml 640 32 > gpurun_out/${T}_layer_report.txt 2>&1
 python3 tools/layer_report.py yolov10m_3D.yaml 640 32 > gpurun_out/${T}_layer_report_m3d.txt 2>&1
