@@ -894,6 +894,11 @@ def test_bench_main_prints_a_line_for_every_baseline_model(argv, what, capsys):
     roof = out["roofline"]
     assert roof is not None and roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["launches_timed"] >= 1, roof
     assert out["steps_skipped_nonfinite"] == 0
+    # both training legs ran (launch by launch, and replayed from one hipGraph); the headline is the faster one and says which
+    assert out["train_images_per_sec_eager"] > 0 and out["train_images_per_sec_graph"] > 0, "the hipGraph leg did not run"
+    assert out["train_mode"] in ("eager", "hipgraph")
+    assert out["value"] == max(out["train_images_per_sec_eager"], out["train_images_per_sec_graph"])
+    assert abs(out["ms_per_step"] - 1e3 * out["config"]["global_batch"] / out["value"]) < 1e-2 * out["ms_per_step"]
 
 
 def test_l2d_1280_hires_step_eval_and_postprocess():
