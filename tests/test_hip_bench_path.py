@@ -754,6 +754,55 @@ def test_concat_placement_is_bit_identical_to_copying(kind):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name,S", [("yolov10s_3D.yaml", 256), ("yolov10n.yaml", 96)])
+def test_cross_layer_concat_placement_is_bit_identical_and_saves_the_copies(name, S):
+    """tasks._predict_once: from the second forward of an input geometry on, the rows that produce a Concat's skip member (layers 4, 6,
+    10, 13 of the v10 tables: C2f / PSA) write it straight into the concat buffer through their closing 1x1 conv (ops.place_final /
+    final_place).  Same kernels on the same values: loss items, every gradient and the eval output must not differ in a single bit
+    from the run that copies; and the copies must actually be gone (one y3d_copy2d per skip member less)."""
+    import bench
+    is3d = "3D" in name
+    torch.manual_seed(5)
+    model = (y3d.YOLOv10_3DDetectionModel if is3d else y3d.YOLOv10DetectionModel)(name).to(DEV).train()
+    batch = bench.synth_batch(2, S, S, 3, DEV, nc=model.yaml["nc"])
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    L = ops.lib()
+    orig = L.copy2d
+    counts, res = {}, {}
+    old = ops.PLACEMENT
+    try:
+        for flag in (True, False):
+            ops.PLACEMENT = flag
+            model.__dict__.pop("_cat_shapes", None)
+            n = []
+            L.copy2d = lambda *a: (n.append(a[5] * a[6]), orig(*a))[1]
+            outs = []
+            for it in range(2):  # the first pass records the concat layouts, the second places
+                model.load_state_dict(state)
+                model.train()
+                for p_ in model.parameters():
+                    p_.grad = None
+                n.clear()
+                loss, items = model(batch)
+                loss.backward()
+                fwd_copies = len(n)
+                outs.append([items.clone()] + [p_.grad.clone() for p_ in model.parameters() if p_.grad is not None])
+            model.eval()
+            with torch.no_grad():
+                ye = model(batch["img"])["one2one"][0].clone()
+            res[flag], counts[flag] = outs[1] + [ye], fwd_copies
+            for a, b in zip(outs[0], outs[1]):
+                assert torch.equal(a, b), "first (recording) and second (placing) pass differ"
+    finally:
+        L.copy2d = orig
+        ops.PLACEMENT = old
+        model.__dict__.pop("_cat_shapes", None)
+    assert len(res[True]) == len(res[False])
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert counts[True] <= counts[False] - 4, f"copies per training forward: {counts[True]} with placement, {counts[False]} without"
+
+
 S2_SHAPES = [
     # B, H, W, Cin, Cout
     (2, 64, 64, 32, 64),      # the 320 -> 160 layer's geometry in small

@@ -176,7 +176,9 @@ class C2f(nn.Module):
         for i, m in enumerate(self.m):
             feed = m(feed, place=(buf, (2 + i) * self.c)) if isinstance(m, Bottleneck) else m(feed)
             y.append(feed)
-        return self.cv2(cat(y))
+        h = cat(y)
+        with ops.final_place():  # a later Concat row that takes this block's output gets it written in place (tasks._predict_once)
+            return self.cv2(h)
 
 
 class SPPF(nn.Module):
@@ -285,7 +287,9 @@ class PSA(nn.Module):
         a, b = self.cv1(x).split((self.c, self.c), dim=1)
         b = self.attn(b, res=b)
         b = self.ffn[1](self.ffn[0](b), b, 1)
-        return self.cv2(cat((a, b)))
+        h = cat((a, b))
+        with ops.final_place():
+            return self.cv2(h)
 
 
 class SCDown(nn.Module):

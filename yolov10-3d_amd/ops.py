@@ -77,6 +77,34 @@ class place:
         _PLACE = self.prev
 
 
+# cross-layer placement (round 3): a Concat row of the yaml also takes the output of an EARLIER row (the backbone / neck skips: layers 4,
+# 6, 10, 13 of the v10 tables).  tasks._predict_once opens `place_final(buf, off)` around that earlier row; the row's module hands the
+# slot to its LAST kernel with `final_place()` (C2f / C2fCIB / PSA: the closing 1x1 conv), so the skip is written where the concat will
+# read it - 13 -> 8 member copies per forward, 157 -> 33 MB.  A module that never calls final_place() leaves the slot unused (the concat
+# copies that member as before).
+_PLACE_FINAL = None
+
+
+class place_final:
+    def __init__(self, buf, off):
+        self.t = (buf, off) if buf is not None else None
+
+    def __enter__(self):
+        global _PLACE_FINAL
+        self.prev, _PLACE_FINAL = _PLACE_FINAL, self.t
+
+    def __exit__(self, *a):
+        global _PLACE_FINAL
+        _PLACE_FINAL = self.prev
+
+
+def final_place():
+    """`with ops.final_place(): return last_op(...)` inside a module: the pending cross-layer slot (if any) becomes the placement of that op"""
+    global _PLACE_FINAL
+    t, _PLACE_FINAL = _PLACE_FINAL, None
+    return place(*(t or (None, 0)))
+
+
 def concat_buffer(x, C, H=None, W=None):
     """the buffer a group of producers will fill for a channel concat of C channels at x's batch / spatial size, or None"""
     dtype = _COMPUTE_DTYPE
@@ -123,8 +151,9 @@ def grad_slot_tensor(slot):
 
 
 def reset_placement():
-    global _PLACE
+    global _PLACE, _PLACE_FINAL
     _PLACE = None
+    _PLACE_FINAL = None
     _CONCAT_BASE.clear()
     _GRAD_SLOT.clear()
 
@@ -287,7 +316,9 @@ class _PackRegistry:
         e["seen"] = WEIGHT_EPOCH
         if self.epoch != now:
             self.epoch = now
-            stale = [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > self.KEEP]
+            # (not while a hipGraph is being captured: dropping entries changes the table key, and rebuilding the descriptor tables is a
+            # host-to-device copy, which a capture does not allow - entries of a model that is gone wait for the next eager step)
+            stale = [] if torch.cuda.is_current_stream_capturing() else [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > self.KEEP]
             for k in stale:
                 del self.entries[k]
             self._pack_all(geo[5])
@@ -346,8 +377,9 @@ class _QuantRegistry:
         e["seen"] = WEIGHT_EPOCH
         if self.epoch != WEIGHT_EPOCH:
             self.epoch = WEIGHT_EPOCH
-            for k in [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > _PackRegistry.KEEP]:
-                del self.entries[k]
+            if not torch.cuda.is_current_stream_capturing():  # as _PackRegistry.lookup
+                for k in [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > _PackRegistry.KEEP]:
+                    del self.entries[k]
             self._run(list(self.entries.values()))
             for v in self.entries.values():
                 v["ver"] = None

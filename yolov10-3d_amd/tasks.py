@@ -228,13 +228,61 @@ class BaseModel(nn.Module):
         y = []
         ops.reset_placement()
         layers = list(self.model)
+        # cross-layer placement: the second pass over an input geometry knows every Concat row's channel layout and map size (recorded
+        # by the first), so the rows that produce a concat's LATER members (skips from earlier layers) write them in place
+        skips = self.__dict__.get("_skip_plan")
+        if skips is None:
+            skips = self.__dict__["_skip_plan"] = self._skip_members(layers)
+        key = (tuple(x.shape), x.dtype, str(x.device), ops.compute_dtype()) if torch.is_tensor(x) else None
+        shapes_all = self.__dict__.setdefault("_cat_shapes", {})
+        shapes = shapes_all.get(key) if (key is not None and ops.PLACEMENT) else None
+        rec, bufs = {}, {}
         for idx, m in enumerate(layers):
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            with ops.place(self._concat_slot(layers, idx, x, y), 0):
+            fin = (None, 0)
+            if shapes is not None and idx in skips and skips[idx][0] in shapes and torch.is_tensor(x) and x.is_cuda:
+                k, pos = skips[idx]
+                tot, cs, h, w = shapes[k]
+                if k not in bufs:
+                    bufs[k] = ops.concat_buffer(x, tot, h, w)
+                if bufs[k] is not None:
+                    fin = (bufs[k], sum(cs[:pos]))
+            if type(m) is Concat and isinstance(x, (list, tuple)) and all(torch.is_tensor(t) and t.dim() == 4 for t in x):
+                rec[idx] = (sum(t.shape[1] for t in x), [t.shape[1] for t in x], x[0].shape[2], x[0].shape[3])
+            slot = bufs.get(idx + 1) if (idx + 1) in bufs and self._first_member_fits(layers, idx, x, bufs[idx + 1], shapes) else self._concat_slot(layers, idx, x, y)
+            with ops.place(slot, 0), ops.place_final(*fin):
                 x = m(x)
             y.append(x if m.i in self.save else None)
+        if key is not None and key not in shapes_all:
+            shapes_all[key] = rec
         return x
+
+    @staticmethod
+    def _skip_members(layers):
+        """{producer row: (concat row, member position)} for the members of every Concat row that come from an earlier row (not -1);
+        a producer that feeds several concats is planned for the first one only"""
+        plan = {}
+        for k, m in enumerate(layers):
+            if type(m) is Concat and isinstance(m.f, (list, tuple)):
+                for pos, j in enumerate(m.f):
+                    if j != -1:
+                        src = j if j >= 0 else k + j
+                        if 0 <= src < k - 1 and src not in plan:
+                            plan[src] = (k, pos)
+        return plan
+
+    @staticmethod
+    def _first_member_fits(layers, idx, x, buf, shapes):
+        """the pre-allocated buffer of the NEXT row's concat also serves its first member (this row's output, a single-kernel producer)"""
+        m, nxt = layers[idx], layers[idx + 1]
+        if buf is None or shapes is None or (idx + 1) not in shapes or not (type(nxt) is Concat and nxt.f[0] == -1 and m.f == -1):
+            return False
+        if not (type(m) in (Upsample, Conv) and torch.is_tensor(x) and x.dim() == 4):
+            return False
+        tot, cs, h, w = shapes[idx + 1]
+        c = x.shape[1] if type(m) is Upsample else m.conv.out_channels
+        return c == cs[0] and buf.shape[1] == tot and buf.shape[2] == h and buf.shape[3] == w
 
     @staticmethod
     def _concat_slot(layers, idx, x, y):
