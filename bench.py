@@ -166,6 +166,7 @@ def main(argv=None):
                     help="N = 1: do not ALSO time the training step replayed from one hipGraph (graph.GraphedTrainStep).  By default both the "
                          "launch-by-launch loop and the replay are timed over --steps steps each; `value` is the faster of the two (`train_mode` "
                          "says which: the eager loop is bound by the host on a slow CPU, the replay never is), both rates are in the line")
+    ap.add_argument("--no-val-batch", action="store_true", help="skip the second inference leg at the reference's validation batch (2 x --batch, engine/trainer.py:297)")
     ap.add_argument("--infer-mode", default="graph", choices=["graph", "eager"],
                     help="inference leg: replay the eval forward + postprocess from one captured hipGraph per batch (default), or launch eagerly")
     args = ap.parse_args(argv)
@@ -320,7 +321,7 @@ def main(argv=None):
     # is ~200 launches of 3-150 us: enqueued eagerly the host is the bound (tools/eval_audit.py), so the timed loop replays ONE captured
     # hipGraph per batch (yolov10-3d_amd/graph.py; --infer-mode eager keeps the launch-by-launch loop); the eager rate is reported next to it
     model.eval()
-    infer_ips = infer_eager_ips = None
+    infer_ips = infer_eager_ips = infer_val_ips = None
     infer_mode = args.infer_mode
     roof_infer = None
     nc = model.yaml["nc"]
@@ -379,7 +380,19 @@ def main(argv=None):
                 except Exception as e:  # a capture failure must not cost the run its train number
                     log(f"hipGraph capture of the eval forward failed ({type(e).__name__}: {e}); reporting the eager rate")
                     infer_mode = "eager"
-    log(f"infer: {infer_ips:.1f} images/s ({infer_mode}; eager {infer_eager_ips:.1f})" if infer_ips else "infer: skipped")
+            # the reference validates DURING training with twice the training batch (engine/trainer.py:297: test_loader batch_size * 2):
+            # the same leg at that batch, reported next to the batch-B figure (which stays `infer_images_per_sec`, comparable across rounds)
+            if infer_mode == "graph" and world == 1 and not args.no_val_batch:
+                try:
+                    img2 = torch.cat((batch["img"], batches[1 % NBATCH]["img"]), 0)
+                    gf2 = GraphedForward(infer_once, img2)
+                    gf2(gf2.inputs[0])
+                    infer_val_ips = 2 * timed_infer(lambda: gf2(gf2.inputs[0]), args.infer_steps)
+                    del gf2, img2
+                except Exception as e:
+                    log(f"eval leg at the reference's validation batch failed ({type(e).__name__}: {e})")
+    log(f"infer: {infer_ips:.1f} images/s ({infer_mode}; eager {infer_eager_ips:.1f}{'; at the validation batch %d: %.1f' % (2 * B, infer_val_ips) if infer_val_ips else ''})"
+        if infer_ips else "infer: skipped")
 
     if rank == 0:
         res = timer.results().get(k1_key, []) if k1_key is not None else []
@@ -424,7 +437,9 @@ def main(argv=None):
             "train_mode": train_mode, "train_images_per_sec_eager": round(train_ips, 2),
             "train_images_per_sec_graph": round(train_graph_ips, 2) if train_graph_ips else None,
             "infer_images_per_sec": round(infer_ips, 2) if infer_ips else None, "infer_mode": infer_mode if infer_ips else None,
-            "infer_images_per_sec_eager": round(infer_eager_ips, 2) if infer_eager_ips else None, "roofline_infer": roof_infer,
+            "infer_images_per_sec_eager": round(infer_eager_ips, 2) if infer_eager_ips else None,
+            "infer_images_per_sec_val_batch": round(infer_val_ips, 2) if infer_val_ips else None, "infer_val_batch": 2 * B if infer_val_ips else None,
+            "roofline_infer": roof_infer,
             "loss_items": [round(float(v), 5) for v in items.float().cpu()],
             "roofline": roof, "cpu_baseline": cpu,
         }

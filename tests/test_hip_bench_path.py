@@ -946,6 +946,7 @@ def test_bench_main_prints_a_line_for_every_baseline_model(argv, what, capsys):
     # both training legs ran (launch by launch, and replayed from one hipGraph); the headline is the faster one and says which
     assert out["train_images_per_sec_eager"] > 0 and out["train_images_per_sec_graph"] > 0, "the hipGraph leg did not run"
     assert out["train_mode"] in ("eager", "hipgraph")
+    assert out["infer_images_per_sec_val_batch"] > 0 and out["infer_val_batch"] == 2 * out["config"]["global_batch"]
     assert out["value"] == max(out["train_images_per_sec_eager"], out["train_images_per_sec_graph"])
     assert abs(out["ms_per_step"] - 1e3 * out["config"]["global_batch"] / out["value"]) < 1e-2 * out["ms_per_step"]
 
