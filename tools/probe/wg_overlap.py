@@ -1,4 +1,5 @@
-"""A/B of the side-stream weight gradients on the training step (GPU box):  python tools/probe/wg_overlap.py [yaml] [batch]"""
+"""A/B loop of the round-3 experiment "weight gradients on a second stream" (measured, not kept - the `ops.WGRAD_OVERLAP`
+switch it toggles went with the experiment, so at HEAD both settings time the same step):  python tools/probe/wg_overlap.py [yaml] [batch]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
