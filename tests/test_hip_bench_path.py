@@ -725,7 +725,7 @@ def test_mt_pack_weights_matches_single_tensor_packing():
             assert torch.equal(dst.view(torch.int16), ref.view(torch.int16)), (mode, i, tuple(w.shape))
 
 
-@pytest.mark.parametrize("kind", ["c2f", "c2f_shortcut", "sppf", "psa"])
+@pytest.mark.parametrize("kind", ["c2f", "c2f_shortcut", "sppf", "psa", "c2fcib", "c2fcib_lk"])
 def test_concat_placement_is_bit_identical_to_copying(kind):
     """C2f / SPPF producers write straight into their slice of the concat buffer (ops.place); with the switch off every input is copied.
     Same kernels on the same values either way: outputs and gradients must not differ in a single bit.  PSA concatenates a slice of its
@@ -734,7 +734,8 @@ def test_concat_placement_is_bit_identical_to_copying(kind):
     M = import_module("yolov10-3d_amd.modules")
     torch.manual_seed(3)
     mod = {"c2f": lambda: M.C2f(64, 128, 2), "c2f_shortcut": lambda: M.C2f(64, 64, 1, True), "sppf": lambda: M.SPPF(128, 128),
-           "psa": lambda: M.PSA(128, 128)}[kind]().to(DEV).train()
+           "psa": lambda: M.PSA(128, 128), "c2fcib": lambda: M.C2fCIB(64, 64, 2, True, False),
+           "c2fcib_lk": lambda: M.C2fCIB(64, 128, 1, True, True)}[kind]().to(DEV).train()
     x0 = torch.randn(2, mod.cv1.conv.in_channels, 20, 24, device=DEV)
     res = []
     old = ops.PLACEMENT

@@ -174,7 +174,7 @@ class C2f(nn.Module):
             feed = y1
         y = [y0, y1]
         for i, m in enumerate(self.m):
-            feed = m(feed, place=(buf, (2 + i) * self.c)) if isinstance(m, Bottleneck) else m(feed)
+            feed = m(feed, place=(buf, (2 + i) * self.c)) if isinstance(m, (Bottleneck, CIB)) else m(feed)
             y.append(feed)
         h = cat(y)
         with ops.final_place():  # a later Concat row that takes this block's output gets it written in place (tasks._predict_once)
@@ -233,11 +233,12 @@ class CIB(nn.Module):
         )
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
+    def forward(self, x, place=None):
         y = x
         for i in range(4):
             y = self.cv1[i](y)
-        return self.cv1[4](y, x, 1) if self.add else self.cv1[4](y)
+        with ops.place(*(place or (None, 0))):  # the closing depth-wise conv writes into the enclosing C2fCIB's concat slice
+            return self.cv1[4](y, x, 1) if self.add else self.cv1[4](y)
 
 
 class C2fCIB(C2f):
