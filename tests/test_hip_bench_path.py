@@ -804,6 +804,54 @@ def test_cross_layer_concat_placement_is_bit_identical_and_saves_the_copies(name
     assert counts[True] <= counts[False] - 4, f"copies per training forward: {counts[True]} with placement, {counts[False]} without"
 
 
+S2_FWD_SHAPES = [
+    # B, H, W, Cin, Cout   (input size; 3x3 stride 2 pad 1)
+    (2, 64, 64, 32, 64),      # the 320 -> 160 layer of S in small: whole tiles
+    (3, 34, 38, 32, 64),      # ragged output tiles (17 x 19)
+    (2, 17, 21, 16, 32),      # odd input: the last output row / column reads one row / column of padding (N widths)
+    (1, 40, 24, 24, 64),      # input channels not a multiple of 32: zero-filled chunks of the 64-byte LDS row
+    (2, 33, 47, 8, 24),       # one chunk of input channels, output channels not a multiple of 16
+    (4, 96, 160, 32, 48),     # more tiles than workgroups per XCD slot; three output-channel tiles
+]
+
+
+@pytest.mark.parametrize("shape", S2_FWD_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3s2_forward_narrow_kernel_exact(shape):
+    """csrc/conv3x3_small.hip, ST = 2 (parity-plane halo): the stride-2 forward of the first stages through y3d_conv2d_fwd - outputs AND
+    BatchNorm partial sums exact on small-integer operands against fp32 conv2d - and through y3d_conv2d_fwd_affine (folded BatchNorm +
+    SiLU epilogue) against the same conv followed by the affine map, within one bf16 rounding"""
+    L, st, dt = y3d.lib(), ops.stream(), BF16
+    B, H, W, Cin, Cout = shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator().manual_seed(sum(shape))
+    x = _sparse_int((B, Cin, H, W), g, 0.25)
+    w = _sparse_int((Cout, Cin, 3, 3), g, 0.25)
+    bf = torch.bfloat16
+    xin = ops.nhwc_empty(B, Cin, H, W, bf, DEV)
+    xin.copy_(x.to(DEV))
+    wd = w.to(DEV).contiguous()
+    wp = torch.empty(Cout * 9 * Cin, dtype=bf, device=DEV)
+    L.pack_weight_fwd(dt, wd.data_ptr(), wp.data_ptr(), Cout, Cin, Cin, 3, 3, st)
+    sb, sh, sw = ops.s3(xin)
+    nblk = L.conv2d_stat_rows(dt, B, H, W, Cin, Cout, 1, 3, 3, 2, 1)
+    part = torch.full((nblk, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+    y = ops.nhwc_empty(B, Cout, Ho, Wo, bf, DEV)
+    y.fill_(7.0)
+    L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, 1, 3, 3, 2, 1, part.data_ptr(), st)
+    ref = F.conv2d(x, w, stride=2, padding=1)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(y.float().cpu(), ref), f"forward: {int((y.float().cpu() != ref).sum())} of {ref.numel()} outputs differ"
+    s_ref = torch.stack((ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))), 1)
+    assert torch.equal(part.double().sum(0).cpu(), s_ref), "BatchNorm partial sums differ"
+    sc = (0.5 + torch.rand(Cout, generator=g)).to(DEV)
+    sf = (torch.rand(Cout, generator=g) - 0.5).to(DEV)
+    z = ops.nhwc_empty(B, Cout, Ho, Wo, bf, DEV)
+    L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), sc.data_ptr(), sf.data_ptr(), 1, z.data_ptr(), Cout, Ho, Wo, Cout, 1, 3, 3, 2, 1, st)
+    zr = F.silu(ref * sc.cpu().view(1, -1, 1, 1) + sf.cpu().view(1, -1, 1, 1))
+    err = (z.float().cpu() - zr).abs().max() / zr.abs().max()
+    assert float(err) < 6e-3, f"affine epilogue: {float(err):.2e}"
+
+
 S2_SHAPES = [
     # B, H, W, Cin, Cout
     (2, 64, 64, 32, 64),      # the 320 -> 160 layer's geometry in small

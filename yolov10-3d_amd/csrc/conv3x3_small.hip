@@ -24,7 +24,8 @@ struct SmP {
   const bf16_t* res;           // optional residual added after the activation (Bottleneck shortcut, block.py:342), pixel stride rsw
   int act, rsw;
   int xsb, xsh, xsw, ysw;
-  int B, H, W, Cin, Cout, Ktot, flip, rows;
+  int B, H, W, Cin, Cout, Ktot, flip, rows;  // H, W: OUTPUT map
+  int Hi, Wi;                                 // input map (= H, W at stride 1)
   int nty, ntx, ntiles;
   unsigned xbytes, ybytes;
 };
@@ -37,9 +38,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned sm_u32x2;
 // for 64-byte rows.
 template <int CB> __device__ __forceinline__ int sm_swz(int row) { return CB == 128 ? (row & 7) : ((row >> 2) & 3); }
 
-template <int CB, int NCT, bool AFF>  // NCT: 16-channel output tiles (Cout <= 16 NCT); AFF: folded BatchNorm + SiLU (+ residual) epilogue
+// ST = 2 (round 3): the stride-2 forward of the first stages (32 -> 64 at 320x320: 315 MB of tensors took 146 us on the generic implicit
+// GEMM).  The (2 TH + 1) x 33 input halo of an 8 x 16 output tile is laid out in LDS as FOUR PARITY PLANES of 9 x 17 pixels (plane =
+// (row & 1, column & 1) of the halo coordinate): tap (r, q) of output pixel (y, x) reads halo (2y + r, 2x + q) = plane (r & 1, q & 1),
+// position (y + (r >> 1), x + (q >> 1)) - sixteen consecutive lanes read sixteen consecutive pixels of one plane row, exactly the
+// stride-1 access pattern, with the same swizzle.  Only the slot -> source-pixel map of the DMA plan and the tap offsets differ.
+template <int CB, int NCT, bool AFF, int ST>  // NCT: 16-channel output tiles (Cout <= 16 NCT); AFF: folded BatchNorm + SiLU (+ residual) epilogue
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
-  constexpr int TH = 8, HW = 18, NPIX = (TH + 2) * HW;          // 180 halo pixels
+  constexpr int TH = 8;
+  constexpr int HW = ST == 1 ? 18 : 17;                         // pixels per row of a halo plane
+  constexpr int PP = (ST == 1 ? TH + 2 : TH + 1) * HW;          // pixel slots per plane: 180 / 153
+  constexpr int NPIX = ST == 1 ? PP : 4 * PP;                   // 180 halo pixels / 612 slots (561 real ones)
   constexpr int SPI = 1024 / CB;                                // pixel slots per DMA instruction (8 or 16)
   constexpr int NINST = (NPIX + SPI - 1) / SPI;                 // 23 / 12
   constexpr int NI = (NINST + 3) / 4;                           // per wave (the last ones may be dummies into the slack)
@@ -78,20 +87,28 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   for (int n = 0; n < NI; ++n) {
     const int ii = wave * NI + n;
     const int P = ii * SPI + lane / CPR, cpos = lane % CPR;
-    const int row = P / HW, col = P - row * HW;
+    int row, col;
+    bool pv = P < NPIX;
+    if (ST == 1) {
+      row = P / HW; col = P - row * HW;
+    } else {
+      const int pl = P / PP, rem = P - pl * PP, pr = rem / HW, pc = rem - pr * HW;
+      row = 2 * pr + (pl >> 1); col = 2 * pc + (pl & 1);  // halo coordinate relative to input pixel (2 y0 - 1, 2 x0 - 1)
+      pv = pv && row <= 2 * TH && col <= 32;
+    }
     p_off[n] = (row - 1) * p.xsh + (col - 1) * p.xsw + ((cpos ^ sm_swz<CB>(P)) << 3);
-    p_rc[n] = (((P < NPIX) & ((cpos ^ sm_swz<CB>(P)) * 8 < Cin) ? row : 255) << 8) | col;  // the chunk this lane FETCHES must hold real channels
+    p_rc[n] = ((pv & ((cpos ^ sm_swz<CB>(P)) * 8 < Cin) ? row : 255) << 8) | col;  // the chunk this lane FETCHES must hold real channels
   }
   auto issue = [&](int t, int buf) {
     int b, y0, x0;
     const bool live = t < p.ntiles;
     decode(live ? t : 0, b, y0, x0);
-    const int base = b * p.xsb + y0 * p.xsh + x0 * p.xsw;
-    const int hlim = live ? p.H : 0;
+    const int base = b * p.xsb + ST * y0 * p.xsh + ST * x0 * p.xsw;
+    const int hlim = live ? p.Hi : 0;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int r = p_rc[n] >> 8, c = p_rc[n] & 255;
-      const bool ok = ((unsigned)(y0 - 1 + r) < (unsigned)hlim) & ((unsigned)(x0 - 1 + c) < (unsigned)p.W);
+      const bool ok = ((unsigned)(ST * y0 - 1 + r) < (unsigned)hlim) & ((unsigned)(ST * x0 - 1 + c) < (unsigned)p.Wi);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sH + buf * TILE + (wave * NI + n) * 1024), 16,
                                                ok ? (unsigned)(base + p_off[n]) * 2u : OOB, 0, 0, 0);
     }
@@ -146,7 +163,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const int P = (wave * 2 + r + tr) * HW + tq + lp;
+          const int P = ST == 1 ? (wave * 2 + r + tr) * HW + tq + lp
+                                : (((tr & 1) << 1) | (tq & 1)) * PP + (wave * 2 + r + (tr >> 1)) * HW + (tq >> 1) + lp;
           fb[r] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hb + P * CB + (((ks * 4 + lq) ^ sm_swz<CB>(P)) << 4)));
         }
 #pragma unroll
@@ -218,16 +236,20 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   }
 }
 
-template <int CB, int NCT, bool AFF>
+constexpr size_t sm_lds(int cb, int nct, int st) {
+  const int spi = 1024 / cb, ninst = ((st == 1 ? 180 : 612) + spi - 1) / spi, ni = (ninst + 3) / 4;
+  return (size_t)9 * nct * 16 * cb + 2 * (size_t)ni * 4 * 1024;
+}
+
+template <int CB, int NCT, bool AFF, int ST = 1>
 void sm_launch(const SmP& p, int grid, hipStream_t st) {
-  constexpr int SPI = 1024 / CB, NINST = (180 + SPI - 1) / SPI, NI = (NINST + 3) / 4;
-  const size_t lds = (size_t)9 * NCT * 16 * CB + 2 * (size_t)NI * 4 * 1024;
+  const size_t lds = sm_lds(CB, NCT, ST);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT, AFF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT, AFF>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT, AFF, ST>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -264,7 +286,7 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
   Y3D_CHECK(!(scale && part) && (scale || !res), "conv3x3_small: the affine epilogue carries no BatchNorm partials; a residual needs the affine form");
   Y3D_CHECK(!res || (((uintptr_t)res & 7) == 0 && rsw % 4 == 0 && (long)B * H * W * rsw < (1L << 31)), "conv3x3_small: residual alignment");
   p.xsb = (int)xsb; p.xsh = (int)xsh; p.xsw = (int)xsw; p.ysw = (int)ysw;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ktot = Ktot; p.flip = flip; p.rows = rows;
+  p.B = B; p.H = H; p.W = W; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout; p.Ktot = Ktot; p.flip = flip; p.rows = rows;
   p.nty = cdiv(H, 8); p.ntx = cdiv(W, 16); p.ntiles = B * p.nty * p.ntx;
   p.xbytes = (unsigned)xext; p.ybytes = (unsigned)yext;
   const int nct = cdiv(Cout, 16);
@@ -284,6 +306,54 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
   if (scale) { if (cb == 128) { SM_GO(128, true) } else { SM_GO(64, true) } }
   else { if (cb == 128) { SM_GO(128, false) } else { SM_GO(64, false) } }
 #undef SM_GO
+  Y3D_LAUNCH_CHECK();
+  return Y3D_OK;
+}
+
+// ---- stride 2 (forward only): input (B, H, W, Cin <= 32), output (B, Ho, Wo, Cout <= 64), 3x3, pad 1 --------------------------------
+int y3d_conv3x3_small_s2_ok(int dtype, int B, int H, int W, int Cin, int Cout) {
+  if (!y3d_get_stream1x1() || dtype != Y3D_BF16 || Cin < 8 || Cin > 32 || Cin % 8 != 0 || Cout > 64 || Cout < 8 || Cout % 4 != 0) return 0;
+  if (H < 8 || W < 16) return 0;
+  return 1;
+}
+
+int y3d_conv3x3_small_s2_rows(int B, int H, int W, int Cin, int Cout) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long ntiles = (long)B * cdiv(Ho, 8) * cdiv(Wo, 16);
+  const long grid = 256 * (sm_lds(64, cdiv(Cout, 16), 2) <= 80 * 1024 ? 2 : 1);
+  return (int)(grid < ntiles ? grid : ntiles);
+}
+
+int y3d_conv3x3_small_s2_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
+                                long ysw, float* part, int rows, const float* scale, const float* shift, int act, void* stream) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  Y3D_CHECK(((uintptr_t)x & 15) == 0 && xsb % 8 == 0 && xsh % 8 == 0 && xsw % 8 == 0 && ((uintptr_t)w & 15) == 0 && Ktot % 8 == 0 &&
+                ((uintptr_t)y & 7) == 0 && ysw % 4 == 0, "conv3x3_small_s2: operand alignment");
+  const long xext = ((long)(B - 1) * xsb + (long)(H - 1) * xsh + (long)(W - 1) * xsw + Cin) * 2;
+  const long yext = (((long)B * Ho * Wo - 1) * ysw + Cout) * 2;
+  Y3D_CHECK(xext < (1L << 32) - 64 && yext < (1L << 32) - 64 && (long)B * xsb < (1L << 31) && (long)B * Ho * Wo * ysw < (1L << 31),
+            "conv3x3_small_s2: tensors beyond 32-bit byte offsets");
+  Y3D_CHECK(!(scale && part), "conv3x3_small_s2: the affine epilogue carries no BatchNorm partials");
+  SmP p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.part = part;
+  p.scale = scale; p.shift = shift; p.act = act; p.res = nullptr; p.rsw = 0;
+  p.xsb = (int)xsb; p.xsh = (int)xsh; p.xsw = (int)xsw; p.ysw = (int)ysw;
+  p.B = B; p.H = Ho; p.W = Wo; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout; p.Ktot = Ktot; p.flip = 0; p.rows = rows;
+  p.nty = cdiv(Ho, 8); p.ntx = cdiv(Wo, 16); p.ntiles = B * p.nty * p.ntx;
+  p.xbytes = (unsigned)xext; p.ybytes = (unsigned)yext;
+  const int nct = cdiv(Cout, 16);
+  const int grid = y3d_conv3x3_small_s2_rows(B, H, W, Cin, Cout);
+  Y3D_CHECK(!part || rows == grid, "conv3x3_small_s2: the partial buffer must have y3d_conv2d_stat_rows rows (%d given, %d written)", rows, grid);
+  hipStream_t st = (hipStream_t)stream;
+#define SM_GO2(AFF)                                                      \
+  switch (nct) {                                                         \
+    case 1: sm_launch<64, 1, AFF, 2>(p, grid, st); break;                \
+    case 2: sm_launch<64, 2, AFF, 2>(p, grid, st); break;                \
+    case 3: sm_launch<64, 3, AFF, 2>(p, grid, st); break;                \
+    default: sm_launch<64, 4, AFF, 2>(p, grid, st); break;               \
+  }
+  if (scale) { SM_GO2(true) } else { SM_GO2(false) }
+#undef SM_GO2
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }

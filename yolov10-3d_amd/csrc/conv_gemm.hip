@@ -783,6 +783,10 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
                              long ysw, float* part, int rows, int flip, const float* scale, const float* shift, int act, const void* res, long rsw,
                              void* stream);
 int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout);
+int y3d_conv3x3_small_s2_ok(int dtype, int B, int H, int W, int Cin, int Cout);
+int y3d_conv3x3_small_s2_rows(int B, int H, int W, int Cin, int Cout);
+int y3d_conv3x3_small_s2_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cin, int Cout, const void* w, int Ktot, void* y,
+                                long ysw, float* part, int rows, const float* scale, const float* shift, int act, void* stream);
 int y3d_conv1x1_stream_rows(long M, int K, int N, int G = 1);
 extern "C" int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int groups, int kh, int kw, int stride, int pad);
 // wgrad3x3_small.hip
@@ -836,6 +840,8 @@ int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int 
     return y3d_conv1x1_stream_rows((long)B * H * W, Cin / groups, Cout / groups, groups);
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && groups == 1 && y3d_conv3x3_small_ok(dtype, B, H, W, Cin, Cout, 1))
     return y3d_conv3x3_small_rows(B, H, W, Cin, Cout);
+  if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && y3d_conv3x3_small_s2_ok(dtype, B, H, W, Cin, Cout))
+    return y3d_conv3x3_small_s2_rows(B, H, W, Cin, Cout);
   int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, B, H, W, Cin / groups, Cout / groups, groups, kh, kw, stride, pad) : 0;
   if (th) return B * cdiv(H, th) * cdiv(W, 16);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
@@ -917,6 +923,10 @@ static int conv2d_fwd_impl(int dtype, const void* x, int64_t xsb, int64_t xsh, i
       return y3d_conv3x3_small_launch(x, xsb, xsh, xsw, B, H, W, Cin, Cout, w_packed, p.Ktot, y, ysw, stat_partials, rows, 0, scale, shift, act, res, rsw, stream);
   }
   Y3D_CHECK(!res, "conv2d_fwd_affine_res: no kernel with a residual epilogue takes this geometry (ask y3d_conv2d_fwd_affine_res_ok first)");
+  if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && !bias && y3d_conv3x3_small_s2_ok(dtype, B, H, W, Cin, Cout)) {
+    const int rows = stat_partials ? y3d_conv2d_stat_rows(dtype, B, H, W, Cin, Cout, groups, kh, kw, stride, pad) : 1;
+    return y3d_conv3x3_small_s2_launch(x, xsb, xsh, xsw, B, H, W, Cin, Cout, w_packed, p.Ktot, y, ysw, stat_partials, rows, scale, shift, act, stream);
+  }
   if (!bias && g_tile_kernels) {
     int th = y3d_tile_height(dtype, B, H, W, p.Cg, p.Cn, groups, kh, kw, stride, pad);
     if (th) return y3d_conv3x3_tile_launch(dtype, th, x, xsb, xsh, xsw, B, H, W, p.Cg, p.Cn, groups, w_packed, p.Ktot, y, ysw, stat_partials, 0, scale, shift, act, stream);
