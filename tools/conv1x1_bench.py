@@ -78,7 +78,10 @@ def run(L, st, dt, B, H, Cin, Cout, reps, stream_on):
 
 
 def main():
+    global SHAPES
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    if len(sys.argv) > 2:  # "H,Cin,Cout;H,Cin,Cout;..."
+        SHAPES = [tuple(int(v) for v in t.split(",")) for t in sys.argv[2].split(";")]
     L, st, dt = y3d.lib(), ops.stream(), BF16
     B = 32
     print(f"{'shape':>22} {'fwd old':>9} {'fwd new':>9} {'TB/s':>6} {'dgrad old':>10} {'dgrad new':>10} {'TB/s':>6} {'wgrad old':>10} {'wgrad new':>10} {'TF/s':>6}  equal")
