@@ -1,0 +1,82 @@
+// Energy per FLOP of the two bf16 MFMA shapes at the package power limit (round 3): a synthetic loop with the operand
+// traffic of the resident-halo conv kernel - fragments read from LDS (random bf16 data), register-blocked MFMAs, nothing else.
+//   mode 0: v_mfma_f32_16x16x32_bf16, 4 x 4 blocking: 8 x ds_read_b128 feed 16 MFMAs (262 144 FLOP)   - the shape of conv3x3_wide3
+//   mode 1: v_mfma_f32_32x32x16_bf16, 2 x 2 blocking: 4 x ds_read_b128 feed  4 MFMAs (131 072 FLOP) x 2 k-steps = the same FLOPs, the same
+//           8 reads - but every operand register feeds 32 instead of 16 output columns (half the register-file reads per FLOP)
+// 256 workgroups x 512 threads (2 waves per SIMD), run for ~3 s per mode while rocm-smi is polled from the shell script next to it.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void mfma_loop(const uint4* __restrict__ src, float* __restrict__ out, int iters) {
+  __shared__ uint4 lds[4096];  // 64 KB of operand data
+  for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = src[(blockIdx.x * 4096 + i) & 0xfffff];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc_sum = 0.f;
+  if (MODE == 0) {
+    f32x4_t acc[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = __builtin_bit_cast(bf16x8_t, lds[(wave * 512 + it * 64 + a * 64 + lane) & 4095]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = __builtin_bit_cast(bf16x8_t, lds[(wave * 512 + it * 64 + 256 + b * 64 + lane) & 4095]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc_sum += acc[a][b][0] + acc[a][b][3];
+  } else {
+    f32x16_t acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = __builtin_bit_cast(bf16x8_t, lds[(wave * 512 + it * 64 + ks * 128 + a * 64 + lane) & 4095]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = __builtin_bit_cast(bf16x8_t, lds[(wave * 512 + it * 64 + 256 + ks * 128 + b * 64 + lane) & 4095]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc_sum += acc[a][b][0] + acc[a][b][15];
+  }
+  if (acc_sum == 12345.678f) out[blockIdx.x] = acc_sum;  // keep the loop alive
+}
+
+int main(int argc, char** argv) {
+  const int mode = argc > 1 ? atoi(argv[1]) : 0;
+  const int zero = argc > 2 ? atoi(argv[2]) : 0;
+  const double secs = argc > 3 ? atof(argv[3]) : 3.0;
+  std::vector<unsigned short> h(8u << 20);
+  unsigned s = 12345;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 65536.f - 0.5f; union { float f; unsigned u; } c; c.f = f; v = zero ? 0 : (unsigned short)(c.u >> 16); }
+  void* d; float* o;
+  hipMalloc(&d, h.size() * 2); hipMalloc(&o, 4096);
+  hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  const int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&]() { if (mode == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters); else hipLaunchKernelGGL(mfma_loop<1>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters); };
+  run(); hipDeviceSynchronize();
+  double total_ms = 0; int n = 0;
+  while (total_ms < secs * 1e3) {
+    hipEventRecord(e0); run(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); total_ms += ms; ++n;
+  }
+  const double flop = 256.0 * 8 * iters * 262144.0;
+  printf("mode %d (%s) %s operands: %.3f ms per launch, %.0f TFLOP/s\n", mode, mode ? "32x32x16, 2x2 blocking" : "16x16x32, 4x4 blocking", zero ? "zero" : "random", total_ms / n,
+         flop / (total_ms / n * 1e-3) / 1e12);
+  return 0;
+}
