@@ -53,6 +53,30 @@ __global__ __launch_bounds__(512, 1) void mfma_loop(const uint4* __restrict__ sr
     }
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc_sum += acc[a][b][0] + acc[a][b][15];
   }
+  if (MODE == 2) {
+    // fp8 e4m3 x fp8 e4m3, K = 128 per instruction: 4 x the FLOPs of the bf16 16x16x32 shape for 2 x the operand bytes
+    typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+    f32x4_t acc[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+      i32x8_t fa[4], fb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint4 lo = lds[(wave * 512 + it * 64 + a * 64 + lane) & 4095], hi = lds[(wave * 512 + it * 64 + a * 64 + lane + 2048) & 4095];
+        fa[a] = (i32x8_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint4 lo = lds[(wave * 512 + it * 64 + 256 + b * 64 + lane) & 4095], hi = lds[(wave * 512 + it * 64 + 256 + b * 64 + lane + 2048) & 4095];
+        fb[b] = (i32x8_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[a], fb[b], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc_sum += acc[a][b][0] + acc[a][b][3];
+  }
   if (acc_sum == 12345.678f) out[blockIdx.x] = acc_sum;  // keep the loop alive
 }
 
@@ -68,15 +92,20 @@ int main(int argc, char** argv) {
   hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   const int iters = 20000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto run = [&]() { if (mode == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters); else hipLaunchKernelGGL(mfma_loop<1>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters); };
+  auto run = [&]() {
+    if (mode == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters);
+    else if (mode == 1) hipLaunchKernelGGL(mfma_loop<1>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters);
+    else hipLaunchKernelGGL(mfma_loop<2>, dim3(256), dim3(512), 0, 0, (const uint4*)d, o, iters);
+  };
   run(); hipDeviceSynchronize();
   double total_ms = 0; int n = 0;
   while (total_ms < secs * 1e3) {
     hipEventRecord(e0); run(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); total_ms += ms; ++n;
   }
-  const double flop = 256.0 * 8 * iters * 262144.0;
-  printf("mode %d (%s) %s operands: %.3f ms per launch, %.0f TFLOP/s\n", mode, mode ? "32x32x16, 2x2 blocking" : "16x16x32, 4x4 blocking", zero ? "zero" : "random", total_ms / n,
+  const double flop = 256.0 * 8 * iters * 262144.0 * (mode == 2 ? 4 : 1);
+  const char* names[3] = {"bf16 16x16x32, 4x4 blocking", "bf16 32x32x16, 2x2 blocking", "fp8 e4m3 16x16x128 (f8f6f4, unit scales), 4x4 blocking"};
+  printf("mode %d (%s) %s operands: %.3f ms per launch, %.0f TFLOP/s\n", mode, names[mode], zero ? "zero" : "random", total_ms / n,
          flop / (total_ms / n * 1e-3) / 1e12);
   return 0;
 }

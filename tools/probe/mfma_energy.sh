@@ -1,6 +1,6 @@
 # on the GPU box:  bash tools/probe/mfma_energy.sh   (tools/probe/bin/mfma_energy built by: hipcc -O3 --offload-arch=gfx950 tools/probe/mfma_energy.cpp)
 cd $GRAFT_REPO_ROOT
-for zero in 0 1; do for mode in 0 1; do
+for zero in 0 1; do for mode in 0 1 2; do
   ./tools/probe/bin/mfma_energy $mode $zero 4 &
   pid=$!
   sleep 2.5
