@@ -42,10 +42,20 @@ def test_invalid_arguments_raise_python_exceptions():
 
 
 def test_no_cpu_fallback():
+    """no value of the path is ever computed on the host: the kernel wrappers raise for host tensors, and a MODULE handed one (the
+    reference constructor's stride probe, nn/tasks.py:300-310) answers with a meta tensor - a shape without data"""
     import torch
-    from yolov10_3d_amd import modules as M
+    from yolov10_3d_amd import modules as M, ops
+    m = M.Conv(8, 8, 3)
+    x = torch.randn(1, 8, 4, 4)
     with pytest.raises(y3d.Y3DError):
-        M.Conv(8, 8, 3)(torch.randn(1, 8, 4, 4))
+        ops.ConvBNActFn.apply(x, m.conv.weight, m.bn.weight, m.bn.bias, None, 0, m)
+    with pytest.raises(y3d.Y3DError):
+        ops.conv_bn_act_eval(x, m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, 3, 1, 1, 1, True, 1e-3)
+    y = m(x)
+    assert y.device.type == "meta" and tuple(y.shape) == (1, 8, 4, 4)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        y.cpu()  # "Cannot copy out of meta tensor; no data!"
 
 
 def test_no_kernel_needs_scratch():

@@ -922,6 +922,39 @@ def test_topk_selection_ties_and_sizes(HW, K):
         assert torch.equal(idx.cpu().long(), ref), f"{dt}: rows {(idx.cpu().long() != ref).any(1).nonzero().flatten().tolist()} differ"
 
 
+def test_topk_with_nan_scores_writes_every_slot():
+    """a diverged model hands the eval head NaN logits: the selection treats a NaN as the largest key (as torch.topk does) and the rank
+    sort uses the same total order, so every output slot is written with a distinct in-range index (round-3 advisor finding: with float
+    compares all NaNs ranked 0 and the unwritten slots were read as anchor indices - out-of-bounds gathers)"""
+    from yolov10_3d_amd import ops
+    from yolov10_3d_amd.loss import v10_3Dpostprocess
+    torch.manual_seed(5)
+    B, HW, nc, K = 3, 1600, 3, 50
+    maps = torch.randn(B, HW, nc)
+    nan_cells = torch.tensor([7, 100, 101, 900, 1599])
+    maps[0, nan_cells] = float("nan")
+    maps[1] = float("nan")
+    idx = torch.full((B, K), -7, dtype=torch.int32, device=DEV)
+    m = maps.to(DEV)
+    ops.lib().topk_cells(ops.code(torch.float32), m.data_ptr(), nc, B, HW, nc, K, idx.data_ptr(), ops.stream())
+    idx = idx.cpu().long()
+    for b in range(B):
+        assert idx[b].min() >= 0 and idx[b].max() < HW and idx[b].unique().numel() == K
+    assert idx[0, :5].tolist() == nan_cells.tolist()          # NaNs first, lowest index first
+    assert idx[1].tolist() == list(range(K))                  # all NaN: the K lowest indices
+    best = maps[0].max(-1)[0]
+    best[nan_cells] = float("inf")
+    assert torch.equal(idx[0], torch.sort(best, descending=True, stable=True)[1][:K])
+    assert torch.equal(idx[2], torch.sort(maps[2].max(-1)[0], descending=True, stable=True)[1][:K])
+    # the postprocess (two top-k stages + gathers by the selected indices) on NaN scores: finishes, indices in range
+    preds = torch.randn(2, 2100, 38)
+    preds[0, ::3, :3] = float("nan")
+    preds[1, :, :3] = float("nan")
+    reg, sc, lab = v10_3Dpostprocess(preds.to(DEV), 50, 3)
+    torch.cuda.synchronize()
+    assert reg.shape[:2] == (2, 50) and int(lab.min()) >= 0 and int(lab.max()) < 3
+
+
 def test_postprocess_hires_vs_oracle():
     """1280x1280 (33 600 anchors, BASELINE configs[3]): the score row does not fit LDS and goes through the HBM scratch"""
     from oracle import restate as RS
@@ -1230,11 +1263,11 @@ def test_graphed_train_step_matches_eager_steps():
         else:
             state0 = {k: v.clone() for k, v in model.state_dict().items()}
             step = GraphedTrainStep(model, opt, batches[0])
-            # the warm-up step moved the model: start over from the initial state (and zero momentum) so that both modes run the same three steps
-            model.load_state_dict(state0)
-            opt._state["flat"].zero_()
-            for m in step.convs:
-                m._nbt_pending = 0
+            # constructing the step does not train (round-3 advisor finding): its warm-up steps are undone - parameters, BatchNorm
+            # statistics and counters, momentum, step counts are where they were
+            for k, v in model.state_dict().items():
+                assert torch.equal(v, state0[k]), f"GraphedTrainStep's constructor changed {k}"
+            assert float(opt._state["flat"].abs().max()) == 0 and float(opt._state["norm_clip"].abs().max()) == 0 and opt._steps == 0
             for b in batches:
                 loss, it = step(b)
                 items.append(it.float().cpu().clone())
@@ -1245,6 +1278,53 @@ def test_graphed_train_step_matches_eager_steps():
     for k, v in res["eager"][1].items():
         assert torch.equal(v, res["graph"][1][k]), f"state {k} differs after three steps"
     assert torch.equal(res["eager"][2], res["graph"][2]), "momentum buffers differ"
+
+
+def test_graphed_train_step_reports_target_overflow_and_survives_eager_steps():
+    """round-3 advisor findings on graph.GraphedTrainStep: (1) an image with more boxes than the assigner kernels take (64) is reported
+    after a replay as in the eager loop (the captured pad_targets has no read-back of its own); (2) eager optimizer steps between
+    replays (the fallback for such a batch) do not disturb the graph's gradient pointer table"""
+    from bench import synth_batch
+    from yolov10_3d_amd import loss as PL
+    from yolov10_3d_amd.graph import GraphedTrainStep
+    from yolov10_3d_amd.optim import build_optimizer
+    y3d.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(3)
+    model = y3d.YOLOv10_3DDetectionModel("yolov10n_3D.yaml").to(DEV).train()
+    opt = build_optimizer(model, lr=0.01)
+    b0, b1 = synth_batch(2, 256, 256, 31, DEV), synth_batch(2, 256, 256, 32, DEV)
+    step = GraphedTrainStep(model, opt, b0, label_capacity=256)
+    step(b0)
+    PL.check_target_overflow(wait=True)
+    # six eager steps: more than the depth of the optimizer's rotating pointer buffers
+    for _ in range(6):
+        loss, _ = model(b1)
+        loss.backward()
+        opt.step(max_norm=10.0)
+        opt.zero_grad()
+    ref_model = copy.deepcopy(model)
+    ref_opt = build_optimizer(ref_model, lr=0.01)
+    ref_model.model[-1].restack()
+    loss, it_ref = ref_model(b0)
+    loss.backward()
+    ref_opt.load_state_dict(opt.state_dict())
+    ref_opt.step(max_norm=10.0)
+    _, it = step(b0)
+    torch.cuda.synchronize()
+    assert torch.equal(it, it_ref)
+    for (k, a), b in zip(model.state_dict().items(), ref_model.state_dict().values()):
+        assert torch.equal(a, b), f"replay after eager steps: {k} differs from an eager step on the same state"
+    PL.check_target_overflow(wait=True)
+    # an image with 70 boxes
+    big = {k: v.clone() if torch.is_tensor(v) else v for k, v in b0.items()}
+    n0 = int((b0["batch_idx"] == 0).sum())
+    reps = 70 - n0
+    first = int((b0["batch_idx"] == 0).nonzero()[0])
+    for k in step.box_keys:
+        big[k] = torch.cat((b0[k], b0[k][first:first + 1].expand(reps, *b0[k].shape[1:])), 0)
+    step(big)
+    with pytest.raises(y3d.Y3DError, match="70 ground-truth boxes"):
+        PL.check_target_overflow(wait=True)
 
 
 @pytest.mark.parametrize("mode", ["box_only", "kps_only_l2", "both_l2", "both_unconstrained", "kps_only_unconstrained_top1"])
@@ -1294,3 +1374,120 @@ def test_tal3d_hip_non_default_modes_vs_oracle(mode):
     check(ts, targets[1], 1e-4, "target_scores")
     with pytest.raises(RuntimeError):
         PL.DDDetectionLoss(SimpleNamespace(model=[head], args=SimpleNamespace(**dict(hyp, tal_2d=False, tal_3d=False))), tal_topk=topk)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# drop-in boundary on the device (INTEGRATION.md form A): what the reference's trainer / validator do to rebound modules
+# ---------------------------------------------------------------------------------------------------------
+def _reference_walk(model, x):
+    """the reference's BaseModel._predict_once (nn/tasks.py:117-146): a plain walk of the rows - no placement, no private state"""
+    y = []
+    for m in model.model:
+        if m.f != -1:
+            x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+        x = m(x)
+        y.append(x if m.i in model.save else None)
+    return x
+
+
+def _reference_fuse(model):
+    """what the reference's BaseModel.fuse() (nn/tasks.py:177-205) does to every Conv it finds: `m.conv = fuse_conv_and_bn(m.conv, m.bn)`
+    (utils/torch_utils.py:171-198: a NEW nn.Conv2d with folded weight + bias), `delattr(m, "bn")`, `m.forward = m.forward_fuse`"""
+    for m in model.modules():
+        if isinstance(m, M.Conv) and hasattr(m, "bn"):
+            w, b = y3d.tasks.fuse_conv_and_bn(m.conv.weight.detach(), m.bn.weight.detach(), m.bn.bias.detach(), m.bn.running_mean, m.bn.running_var, m.bn.eps)
+            c = m.conv
+            f = torch.nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, groups=c.groups, bias=True).requires_grad_(False).to(w.device)
+            f.weight.copy_(w)
+            f.bias.copy_(b)
+            m.conv = f
+            delattr(m, "bn")
+            m.forward = m.forward_fuse
+    return model
+
+
+@pytest.mark.parametrize("name", ["yolov10n_3D.yaml", "yolov10n.yaml", "yolov10m_3D.yaml"])
+def test_reference_style_walk_and_fuse_match_eval(name):
+    """(1) the rows walked the reference's way give the package's own forward bit for bit (training maps and eval output: placement is an
+    optimisation, not a semantic); (2) a model folded the reference's way (BaseModel.fuse) runs on `forward_fuse` and reproduces the
+    unfolded eval forward (fp32 mode; folding moves the BatchNorm scale into the weights, so equal up to rounding)"""
+    from bench import synth_batch
+    y3d.set_compute_dtype(torch.float32)
+    try:
+        torch.manual_seed(0)
+        model = y3d.DetectionModel(name).to(DEV).train()
+        img = synth_batch(2, 256, 256, 1, DEV)["img"]
+        state = copy.deepcopy(model.state_dict())
+        own = model(img)
+        model.load_state_dict(state)
+        ref = _reference_walk(model, img)
+        for a, b in zip(own["one2many"] + own["one2one"], ref["one2many"] + ref["one2one"]):
+            assert torch.equal(a, b)
+        model.eval()
+        with torch.no_grad():
+            y_own = model(img)["one2one"][0].clone()
+            y_ref = _reference_walk(model, img)["one2one"][0]
+            assert torch.equal(y_own, y_ref)
+            folded = _reference_fuse(copy.deepcopy(model))
+            assert sum(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules()) == 0
+            y_f = _reference_walk(folded, img)["one2one"][0]
+        if hasattr(model.model[-1], "dep"):
+            check_sparse_eval(y_f, y_own, model.model[-1].nc, 1e-3)
+        else:
+            check(y_f, y_own, 1e-3, "folded 2D eval output")
+    finally:
+        y3d.set_compute_dtype(torch.bfloat16)
+
+
+def test_fused_conv_forward_with_residuals_matches_eval():
+    """forward_fuse keeps forward's (x, res, res_mode) signature: Bottleneck / RepVGGDW call their Convs with residual arguments"""
+    y3d.set_compute_dtype(torch.float32)
+    try:
+        torch.manual_seed(3)
+        for mod in (M.Bottleneck(32, 32, True, 1, (3, 3), 1.0), M.RepVGGDW(32), M.CIB(32, 32, True, 1.0, True), M.PSA(128, 128)):
+            mod = mod.to(DEV).eval()
+            for b in mod.modules():
+                if isinstance(b, torch.nn.BatchNorm2d):
+                    b.running_mean.normal_(0, 0.2)
+                    b.running_var.uniform_(0.5, 1.5)
+                    b.weight.data.uniform_(0.5, 1.5)
+                    b.bias.data.normal_(0, 0.2)
+            c = 128 if isinstance(mod, M.PSA) else 32
+            x = torch.randn(2, c, 20, 20, device=DEV)
+            with torch.no_grad():
+                y0 = mod(x)
+                y1 = _reference_fuse(copy.deepcopy(mod))(x)
+            check(y1, y0, 2e-4, type(mod).__name__)
+    finally:
+        y3d.set_compute_dtype(torch.bfloat16)
+
+
+def test_autocast_and_gradscaler_leave_the_step_unchanged():
+    """engine/trainer.py:395-408 runs the step inside torch.autocast and backs a GradScaler-scaled loss: the modules ignore autocast
+    (raw launches in the package's compute dtype) and every backward kernel is linear in the incoming gradient, so after
+    `scaler.unscale_` the gradients are those of the plain step (a power-of-two scale: equal up to values that leave bf16's normal range)"""
+    from bench import synth_batch
+    torch.manual_seed(0)
+    cfg = _tiny_cfg("yolov10s_3D.yaml", **TINY)
+    model = y3d.YOLOv10_3DDetectionModel(cfg).to(DEV).train()
+    batch = synth_batch(2, 128, 128, 1, DEV)
+    state = copy.deepcopy(model.state_dict())
+    loss0, items0 = model(batch)
+    loss0.backward()
+    g0 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(state)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss1, items1 = model(batch)
+    assert torch.equal(items0, items1) and torch.equal(loss0, loss1)
+    scaler.scale(loss1).backward()
+    scaler.unscale_(opt)
+    g1 = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(g0) == set(g1)
+    worst = max(l2_rel(g1[k], g0[k]) for k in g0 if float(g0[k].abs().max()) > 0)
+    assert worst < 2e-3, worst
+    scaler.step(opt)
+    scaler.update()
+    assert scaler.get_scale() == 1024.0  # no inf / NaN found: the scale is kept

@@ -192,3 +192,55 @@ def test_bias_init_2d_and_initialize_weights_match_reference_fixture():
     head = model.model[-1]
     for i in range(3):
         assert torch.equal(head.cls[i][-1].bias.detach()[:3], g3[f"cls/{i}/bias"]) and torch.equal(head.dep[i][-1].bias.detach(), g3[f"dep/{i}/bias"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# drop-in boundary (INTEGRATION.md form A)
+# ---------------------------------------------------------------------------------------------------------
+def _reference_walk(model, x):
+    """the reference's BaseModel._predict_once (nn/tasks.py:117-146) as the trainer would run it over rebound modules: a plain walk of
+    the rows, no placement, no private state"""
+    y = []
+    for m in model.model:
+        if m.f != -1:
+            x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+        x = m(x)
+        y.append(x if m.i in model.save else None)
+    return x
+
+
+@pytest.mark.parametrize("name,want", [("yolov10s_3D.yaml", [8.0, 16.0, 32.0]), ("yolov10m_3D.yaml", [8.0, 16.0]), ("yolov10n.yaml", [8.0, 16.0, 32.0]),
+                                       ("yolov10x.yaml", [8.0, 16.0, 32.0])])
+def test_host_tensor_is_answered_with_shapes_only(name, want):
+    """the reference's constructor probes the strides with forward(torch.zeros(1, ch, 256, 256)) on the HOST (nn/tasks.py:300-310):
+    the modules answer a host tensor with meta tensors of the right shape, so the probe's strides equal the table's - and nothing
+    is computed"""
+    m = y3d.DetectionModel(name)
+    out = _reference_walk(m.train(), torch.zeros(1, 3, 256, 256))
+    maps = out["one2many"]
+    assert all(t.device.type == "meta" for t in maps)
+    assert [256 / t.shape[-2] for t in maps] == want == [float(s) for s in m.stride]
+    head = m.model[-1]
+    assert all(t.shape[1] == head.no for t in maps)
+    ev = _reference_walk(m.eval(), torch.zeros(2, 3, 256, 256))
+    y = ev["one2one"][0]
+    A = sum(t.shape[2] * t.shape[3] for t in maps)
+    assert y.device.type == "meta" and tuple(y.shape) == (2, head.no if hasattr(head, "dep") else 4 + head.nc, A)
+
+
+def test_dropin_against_the_reference():
+    """INTEGRATION.md form A applied verbatim to the imported reference: all twelve shipped yamls build through the reference's own
+    constructors with identical keys / strides / bias_init / folded weights (oracle/check_dropin.py; build container only - the
+    reference does not travel).  Run in a child process: the block rebinds names inside the reference AND torch.nn.Upsample."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("the reference is not present on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "oracle.check_dropin"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert last == {"yamls": 12, "failed": 0}

@@ -96,12 +96,15 @@ __device__ void block_topk(const float* vals, int n, int K, int* out_idx, float*
   }
   __syncthreads();
   for (int j = tid; j < K; j += nt) {
+    // ranked by the SAME total order the selection used (integer keys, index asc): a permutation of 0..K-1 for any input - with float
+    // compares every NaN ranked 0 and some out_idx slots stayed unwritten (round-3 advisor finding)
     const float v = selv[j];
+    const unsigned k = topk_key(v);
     const int i = seli[j];
     int r = 0;
     for (int q = 0; q < K; ++q) {
-      const float v2 = selv[q];
-      r += (v2 > v) || (v2 == v && seli[q] < i);
+      const unsigned k2 = topk_key(selv[q]);
+      r += (k2 > k) || (k2 == k && seli[q] < i);
     }
     out_idx[r] = i;
     if (out_val) out_val[r] = v;

@@ -107,9 +107,11 @@ class FlatGradReducer:
     next launch raises when it sees that).  Gradient accumulation (reference: `accumulate = nbs / batch` micro-steps, trainer.py:383-386,
     DDP `no_sync`) runs the first micro-steps under `with reducer.no_sync():` - no hook counts, nothing is launched, autograd adds
     into `p.grad` as usual - and the last one outside it, followed by `finish()`.  A parameter without a gradient in this step has
-    its slot ZEROED before the collective, whatever an earlier step left there (another rank may own a gradient for it)."""
+    its slot ZEROED before the collective, whatever an earlier step left there (another rank may own a gradient for it) - and after
+    `finish()` EVERY rank holds the reduced sum in `p.grad` for every parameter that has a gradient on some rank."""
 
     CHUNK = 16384
+    MASK_EVERY = 256
 
     def __init__(self, params, bucket_mb: float = 32.0, overlap: bool | None = None, timing: bool = False):
         seen, plist = set(), []
@@ -155,6 +157,7 @@ class FlatGradReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.last_times = None
         self._sync = True
+        self._any, self._nfinish = None, 0  # which parameters have a gradient on some rank (finish())
 
     def no_sync(self):
         """context manager for the non-final micro-steps of gradient accumulation (torch DDP's `no_sync`)"""
@@ -296,8 +299,21 @@ class FlatGradReducer:
             w.wait()
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
+        local = [p.grad is not None for p in self.params]
+        take = local
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # a parameter whose gradient exists on ANOTHER rank only must still receive the reduced sum here (torch DDP hands every rank
+            # the reduced gradient), or this rank's optimizer would skip it and the replicas drift apart (round-3 advisor finding).  Which
+            # parameters have a gradient on some rank is a property of the graph: it is exchanged at the first finish() and re-checked
+            # every MASK_EVERY steps (one small MAX all-reduce + host read; every rank does it at the same step count).
+            if self._any is None or self._nfinish % self.MASK_EVERY == 0:
+                t = torch.tensor(local, dtype=torch.int32, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                self._any = [bool(v) for v in t.cpu().tolist()]
+            self._nfinish += 1
+            take = [a or b for a, b in zip(self._any, local)]
         for i, p in enumerate(self.params):
-            if p.grad is not None:
+            if take[i]:
                 p.grad = self.views[i]
         events = self._events
         self._reset()

@@ -74,6 +74,9 @@ class GraphedTrainStep:
     keeps its count on the device (loss.pad_targets); the optimizer's skip of non-finite steps and AdamW's step count live on the
     device (csrc/optim.hip); pointer tables travel through pinned buffers (optim.PtrUploader).
 
+    Constructing one does NOT train: the warm-up steps it needs run on the first batch and are undone (parameters, BatchNorm buffers,
+    optimizer state and step counts are restored in place before the capture).
+
     Static shapes: the per-box label tensors (`ddp.PER_BOX_KEYS` + `batch_idx`) are padded to `label_capacity` rows (default: 64 per
     image, the assigner's own limit); padding rows carry batch_idx = -1, which no image matches.  `step(batch)` copies the batch into
     the static buffers and replays.  Left to the caller, eagerly, after the replay: `ema.update` (its decay ramp is a host-side
@@ -82,8 +85,10 @@ class GraphedTrainStep:
     counters and the parameter epochs that the eval caches / weight packs key on."""
 
     def __init__(self, model, opt, batch, max_norm: float | None = 10.0, label_capacity: int | None = None, warmup: int = 2):
+        from . import loss as _loss
         from .ddp import PER_BOX_KEYS
         from .modules import Conv
+        from .optim import PtrUploader
         self.model, self.opt, self.max_norm = model, opt, max_norm
         self.box_keys = tuple(k for k in (("batch_idx",) + PER_BOX_KEYS) if k in batch)
         B = batch["img"].shape[0]
@@ -101,20 +106,59 @@ class GraphedTrainStep:
                 self.static[k] = v.detach().clone()
         self.convs = [m for m in model.modules() if isinstance(m, Conv)]
         self._load(batch)
+        # The warm-up below runs REAL steps (the weight packs build their pointer / chunk tables on the second one, with a host-to-device
+        # copy that a capture does not allow; the optimizer builds its tables; the allocator warms up).  They must not train: parameters,
+        # BatchNorm buffers and counters, optimizer state and step counts are snapshotted here and put back (in place: every address
+        # stays) before the capture, so constructing a GraphedTrainStep leaves model and optimizer exactly as it found them.
+        with torch.no_grad():
+            seen, tensors = set(), []
+            for t in list(model.parameters()) + list(model.buffers()):
+                if t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    tensors.append(t)
+            snap = [t.detach().clone() for t in tensors]
+        nbt = [m._nbt_pending for m in self.convs]
+        had_state = opt._state is not None
+        opt_snap = (opt._state["flat"].clone(), opt._state["norm_clip"].clone()) if had_state else None
+        steps0 = opt._steps
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(max(2, warmup)):  # eager steps on the static batch: optimizer state, pointer / chunk tables of the weight
-                # packs (built on the SECOND step, with a host-to-device copy that a capture does not allow), allocator warm
+            for _ in range(max(2, warmup)):
                 self._body()
                 opt.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                for t, v in zip(tensors, snap):
+                    t.copy_(v)
+                if had_state:
+                    opt._state["flat"].copy_(opt_snap[0])
+                    opt._state["norm_clip"].copy_(opt_snap[1])
+                else:
+                    opt._state["flat"].zero_()
+                    opt._state["norm_clip"].zero_()
+        opt._steps = steps0
+        for m, n in zip(self.convs, nbt):
+            m._nbt_pending = n
         cur.wait_stream(side)
         torch.cuda.synchronize()
         ops.bump_weight_epoch()  # the captured forward must contain the weight (re)packing launches of a fresh step
+        # the gradient pointer table of the captured optimizer launches must not live in the optimizer's ROTATING pinned buffers: a few
+        # eager opt.step() calls later (a fallback for an over-capacity batch) would overwrite them and the next replay would read those
+        # pointers (round-3 advisor finding).  The graph gets an uploader of its own; the optimizer builds a new one when it next needs it.
+        st = opt._state
+        st["gup"], st["gkey"] = PtrUploader(len(st["active"]), st["dev"], depth=1), None
+        _loss._CAPTURED_COUNTS.clear()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.items = self._body()
+        self._gup = st["gup"]  # kept alive: the graph's memcpy node reads its pinned buffer at every replay
+        st["gup"], st["gkey"] = None, None
+        # the device words [min(count, cap), true largest per-image count] of the captured pad_targets launches: graph-private static
+        # memory, rewritten by every replay; read back after each one so that an image with more boxes than the kernels take is
+        # reported as in the eager loop, not trained on silently truncated targets (round-3 advisor finding)
+        self.counts = list(_loss._CAPTURED_COUNTS)
+        _loss._CAPTURED_COUNTS.clear()
         for m in self.convs:  # the captured forward counted a step that has not run
             if m.training and m._nbt_pending > 0:
                 m._nbt_pending -= 1
@@ -149,8 +193,12 @@ class GraphedTrainStep:
                 s.copy_(v, non_blocking=True)
 
     def __call__(self, batch=None):
+        from . import loss as _loss
+        _loss.check_target_overflow()  # raises Y3DError a step or two after a replay met an over-capacity image (no host sync)
         if batch is not None:
             self._load(batch)
         self.graph.replay()
+        for n_used, cap in self.counts:
+            _loss.watch_target_count(n_used, cap)
         self._after()
         return self.loss, self.items

@@ -63,15 +63,25 @@ def pad_targets(rows, B, width, scale_xy, cap=TARGET_CAP):
     n_used = torch.empty(2, dtype=torch.int32, device=rows.device)  # [min(count, cap), true count]
     lib().pad_targets(rows.data_ptr(), rows.shape[0], width, B, cap, float(scale_xy[0]), float(scale_xy[1]), out.data_ptr(), n_used.data_ptr(),
                       ops.stream())
-    if not capturing:  # (inside a hipGraph capture the read-back is left out: graph.GraphedTrainStep bounds the rows by its label capacity)
-        host = torch.empty(1, dtype=torch.int32).pin_memory()
-        host.copy_(n_used[1:2], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        _OVERFLOW_PENDING.append((ev, host, cap))
-        if len(_OVERFLOW_PENDING) > 64:  # a caller that never lets the stream drain: look now
-            check_target_overflow(wait=True)
+    if capturing:  # no read-back inside a hipGraph capture: graph.GraphedTrainStep reads this (static) word back after every replay
+        _CAPTURED_COUNTS.append((n_used, cap))
+    else:
+        watch_target_count(n_used, cap)
     return out, n_used[:1]
+
+
+_CAPTURED_COUNTS = []  # (n_used, cap) of the pad_targets launches recorded into the hipGraph being captured
+
+
+def watch_target_count(n_used, cap):
+    """queue an asynchronous read-back of n_used[1] (the true largest per-image box count) for check_target_overflow"""
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(n_used[1:2], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _OVERFLOW_PENDING.append((ev, host, cap))
+    if len(_OVERFLOW_PENDING) > 64:  # a caller that never lets the stream drain: look now
+        check_target_overflow(wait=True)
 
 
 def _flatten_maps(feats):

@@ -28,9 +28,30 @@ def autopad(k, p=None, d=1):
 
 
 def _flush_nbt(module, prefix, keep_vars):
-    if module._nbt_pending:
+    if module._nbt_pending and hasattr(module, "bn"):
         module.bn.num_batches_tracked += module._nbt_pending
         module._nbt_pending = 0
+
+
+# ---- shape probe ----------------------------------------------------------------------------------------------------------------
+# The reference's model constructor finds the detect strides by running forward(torch.zeros(1, ch, 256, 256)) on the HOST
+# (nn/tasks.py:300-310) and reading the shapes of what comes back.  There is no host arithmetic in this package, so a module that is
+# handed a tensor which is not on a HIP device answers with META tensors of its output shape: the probe (and thop / model.info(), which
+# only look at shapes) works, and anything that asks such a result for a VALUE fails inside torch ("Cannot copy out of meta tensor").
+# The kernel wrappers in ops.py keep raising Y3DError for host tensors; no value is ever computed on the host.
+def _bump_epoch_on_load(module, incompatible_keys):
+    """load_state_dict writes through torch (only `_version` counters move): the eval caches notice, a captured hipGraph of the forward
+    (graph.GraphedForward keys on ops.PARAM_EPOCH) would not - so a load moves the parameter epoch too (round-3 advisor finding)"""
+    ops.bump_weight_epoch()
+
+
+def _host(x):
+    t = x[0] if isinstance(x, (list, tuple)) else x
+    return not t.is_cuda
+
+
+def _meta(B, C, H, W):
+    return torch.empty(int(B), int(C), int(H), int(W), device="meta")
 
 
 class Conv(nn.Module):
@@ -53,6 +74,7 @@ class Conv(nn.Module):
         self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
         self._nbt_pending = 0
         self.register_state_dict_pre_hook(_flush_nbt)
+        self.register_load_state_dict_post_hook(_bump_epoch_on_load)
 
     # kernel-facing views of the configuration
     @property
@@ -87,12 +109,27 @@ class Conv(nn.Module):
             return False
         raise Y3DError(f"activation {type(self.act).__name__} has no HIP kernel (SiLU / Identity only)")
 
+    def out_shape(self, x):
+        B, _, H, W = x.shape
+        return B, self.conv.out_channels, (H + 2 * self.p - self.k) // self.s + 1, (W + 2 * self.p - self.k) // self.s + 1
+
     def forward(self, x, res=None, res_mode=0):
         """res_mode 1: act(bn(conv(x))) + res   (Bottleneck / CIB / PSA shortcuts)
            res_mode 2: act(bn(conv(x)) + res)   (RepVGGDW)"""
+        if not x.is_cuda:
+            return _meta(*self.out_shape(x))  # shape probe (see _host)
         return ops.ConvBNActFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias, res, res_mode if res is not None else 0, self)
 
-    forward_fuse = None  # BN folding is done by fuse.py on the packed weights, not by swapping forwards
+    def forward_fuse(self, x, res=None, res_mode=0):
+        """The forward the reference's BaseModel.fuse() switches a Conv to (nn/tasks.py:187-192: `m.conv = fuse_conv_and_bn(m.conv, m.bn)`,
+        `delattr(m, "bn")`, `m.forward = m.forward_fuse`; conv.py:124-126): act(conv(x) + bias) with the folded weight and bias that
+        `self.conv` now carries - the eval kernels' affine epilogue with scale 1 and shift = bias (+ residual as in `forward`)."""
+        if not x.is_cuda:
+            return _meta(*self.out_shape(x))
+        if self.conv.bias is None:
+            raise Y3DError("forward_fuse needs the folded conv (weight + bias) that BaseModel.fuse() installs")
+        return ops.conv_bias_act_eval(x, self.conv.weight, self.conv.bias, self.k, self.s, self.p, self.g, self.has_act, res,
+                                      res_mode if res is not None else 0, self.__dict__.setdefault("_eval_cache", {}))
 
 
 class DWConv(Conv):
@@ -111,6 +148,8 @@ class Concat(nn.Module):
 
     def forward(self, x):
         assert self.d == 1
+        if _host(x):
+            return _meta(x[0].shape[0], sum(t.shape[1] for t in x), *x[0].shape[2:])
         return cat(x)
 
 
@@ -131,6 +170,8 @@ class Upsample(nn.Module):
         self.scale_factor, self.mode = scale_factor, mode
 
     def forward(self, x):
+        if not x.is_cuda:
+            return _meta(x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])
         return ops.Upsample2xFn.apply(x)
 
 
@@ -163,6 +204,8 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
     def forward(self, x):
+        if not x.is_cuda:
+            return self.cv2(x)  # shape probe: spatial size kept, cv2's output channels
         # cv1 and the blocks write into their slices of ONE buffer: the reference's torch.cat (block.py:236) costs nothing
         buf = ops.concat_buffer(x, (2 + len(self.m)) * self.c)
         with ops.place(buf, 0):
@@ -192,6 +235,8 @@ class SPPF(nn.Module):
         self.k = k
 
     def forward(self, x):
+        if not x.is_cuda:
+            return self.cv2(x)  # shape probe
         c_ = self.cv1.conv.out_channels
         buf = ops.concat_buffer(x, 4 * c_)
         ys = []
@@ -285,6 +330,8 @@ class PSA(nn.Module):
         self.ffn = nn.Sequential(Conv(self.c, self.c * 2, 1), Conv(self.c * 2, self.c, 1, act=False))
 
     def forward(self, x):
+        if not x.is_cuda:
+            return self.cv2(x)  # shape probe
         a, b = self.cv1(x).split((self.c, self.c), dim=1)
         b = self.attn(b, res=b)
         b = self.ffn[1](self.ffn[0](b), b, 1)
@@ -403,6 +450,7 @@ class v10Detect3d(nn.Module):
             setattr(self, name, self.build_head([c + extra for c in ch], channels[name + "_c"], out))
         self.o2o_heads = nn.ModuleList([self.cls, self.o2d, self.s2d, self.o3d, self.s3d, self.hd, self.dep, self.dep_un])
         self.o2m_heads = copy.deepcopy(self.o2o_heads)
+        self.register_load_state_dict_post_hook(_bump_epoch_on_load)
 
     def build_head(self, in_channels, mid, out):
         last = mid // 2 if self.half_channels else mid
@@ -580,7 +628,9 @@ class v10Detect3d(nn.Module):
             patches = ops.nhwc_empty(B * K, C, ps, ps, xi.dtype, xi.device)
             sb, sh, sw = ops.s3(xi)
             L.patch_gather(dt, xi.data_ptr(), sb, sh, sw, idx.data_ptr(), patches.data_ptr(), B, H, W, C, K, ps, st)
-            _, mids, s1, s2, _, _ = self._stacks(i) if not self.generic else (None,) * 6
+            # a model folded by the reference's BaseModel.fuse() (no .bn on the branch Convs) runs branch by branch on forward_fuse
+            folded = not hasattr(heads[1][i][0], "bn") if isinstance(heads[1][i][0], Conv) else False
+            _, mids, s1, s2, _, _ = self._stacks(i) if not (self.generic or folded) else (None,) * 6
             if heads is self.o2o_heads and s2 is not None:
                 # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
                 # (channel rows mid..8*mid of the training-time stacks), both unpadded: patch semantics of head.py:706-708
@@ -634,8 +684,19 @@ class v10Detect3d(nn.Module):
                                 (ctypes.c_float * nl)(*[float(s) for s in self.stride.tolist()[:nl]]), B, self.nc, out.data_ptr(), ops.stream())
         return out
 
+    def _probe(self, x):
+        """shape probe (see _host): the reference's constructor reads `forward(zeros)["one2many"]` shapes, nn/tasks.py:306-307"""
+        maps = [_meta(xi.shape[0], self.no, *xi.shape[2:]) for xi in x]
+        if not self.training:
+            return {"one2one": (torch.empty(x[0].shape[0], self.no, sum(m.shape[2] * m.shape[3] for m in maps), device="meta"), maps), "o2o_embs": None}
+        embs = [_meta(xi.shape[0], self.dep[i][0].conv.out_channels if isinstance(self.dep[i][0], Conv) else self.dep[i][0][-1].conv.out_channels,
+                      *xi.shape[2:]) for i, xi in enumerate(x)]
+        return {"one2many": maps, "one2one": list(maps), "o2m_embs": embs, "o2o_embs": list(embs), "depth_maps": torch.empty(1)}
+
     def forward(self, x):
         x = list(x[: self.nl])
+        if _host(x):
+            return self._probe(x)
         if not self.training:
             maps = self.inference_forward_feat([xi.detach() for xi in x], self.o2o_heads)
             return {"one2one": (self.decode(maps), maps), "o2o_embs": None}
@@ -685,6 +746,8 @@ class Detect(nn.Module):
     dynamic = False
     export = False
     shape = None
+    anchors = torch.empty(0)  # head.py:28-29; BaseModel._apply (nn/tasks.py:243-246) moves stride / anchors / strides with the model
+    strides = torch.empty(0)
 
     def __init__(self, nc=80, ch=()):
         super().__init__()
@@ -697,6 +760,7 @@ class Detect(nn.Module):
         self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
         self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
         self.dfl = DFL(self.reg_max)
+        self.register_load_state_dict_post_hook(_bump_epoch_on_load)
 
     def forward_feat(self, x, cv2, cv3):
         ys = []
@@ -725,7 +789,16 @@ class Detect(nn.Module):
                                 (ctypes.c_float * nl)(*[float(s) for s in self.stride.tolist()[:nl]]), B, self.nc, out.data_ptr(), ops.stream())
         return out, ys
 
+    def _probe(self, x, decode):
+        """shape probe (see _host): level maps (B, no, H, W); with `decode` also the (B, 4 + nc, A) inference tensor"""
+        maps = [_meta(xi.shape[0], self.no, *xi.shape[2:]) for xi in x]
+        if not decode:
+            return maps
+        return torch.empty(x[0].shape[0], 4 + self.nc, sum(m.shape[2] * m.shape[3] for m in maps), device="meta"), maps
+
     def forward(self, x):
+        if _host(x):
+            return self._probe(x, not self.training)
         y = self.forward_feat(x, self.cv2, self.cv3)
         return y if self.training else self.inference(y)
 
@@ -750,6 +823,8 @@ class v10Detect(Detect):
         self.one2one_cv3 = copy.deepcopy(self.cv3)
 
     def forward(self, x):
+        if _host(x):
+            return {"one2many": self._probe(x, not self.training), "one2one": self._probe(x, not self.training)}
         one2one = self.forward_feat([xi.detach() for xi in x], self.one2one_cv2, self.one2one_cv3)
         one2many = self.forward_feat(x, self.cv2, self.cv3)
         if self.training:

@@ -425,6 +425,24 @@ def conv_bn_act_eval(x, w, gamma, beta, rm, rv, k, s, p, g, act, eps, cache=None
     return z
 
 
+_IDENT = {}
+
+
+def conv_bias_act_eval(x, w, bias, k, s, p, g, act, res, res_mode, cache):
+    """act(conv(x) + bias) (+res): a Conv after the reference's BaseModel.fuse() (nn/tasks.py:187-192, conv.py:124-126), run as the eval
+    sequence with an IDENTITY BatchNorm - gamma 1, running mean 0, running variance 1, eps 0: scale exactly 1, shift exactly the bias -
+    so the folded model goes through the same kernels (affine conv epilogue, residual forms) as the unfolded eval path."""
+    _require_gpu(x)
+    C = w.shape[0]
+    ident = _IDENT.get((str(w.device), C))
+    if ident is None:
+        ident = _IDENT[(str(w.device), C)] = (torch.ones(C, dtype=torch.float32, device=w.device), torch.zeros(C, dtype=torch.float32, device=w.device))
+    ones, zeros = ident
+    with torch.no_grad():
+        z, _, _ = _cba_forward(x, _w32(w), ones, bias.detach().float(), zeros, ones, k, s, p, g, act, res, res_mode, False, 0.0, 0.0, cache)
+    return z
+
+
 def _eval_consts(cache, kind, w32, g32, b32, rm, rv, ver, dtype, k, g, Cin_g, Cg_pad, Cout, eps):
     """eval-mode constants of one conv, cached in `cache` (a dict owned by the module / stack) until a parameter or buffer changes:
     the packed weights (kind "dense": K-contiguous compute-dtype rows; "dw": tap-major fp32 rows) and the folded BatchNorm

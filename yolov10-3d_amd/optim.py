@@ -60,6 +60,7 @@ class FusedSGD:
         self._state = None
         self._steps = 0
         self.last_norm = None
+        self._pending_load = None
 
     def add_param_group(self, g):
         g = dict(g)
@@ -110,7 +111,32 @@ class FusedSGD:
             "hkey": [(g["lr"], g["weight_decay"], len(g["params"])) for g in self.param_groups],
         }
         self._state = st
+        if self._pending_load is not None:  # load_state_dict() before the first step
+            sd, self._pending_load = self._pending_load, None
+            self.load_state_dict(sd)
         return st
+
+    def state_dict(self):
+        """optimizer state for checkpoint / resume (the reference saves `optimizer.state_dict()`, engine/trainer.py:470-486): the flat
+        state buffers in parameter order (SGD: momentum; AdamW: exp_avg, exp_avg_sq) and the device-side counters [norm, clip
+        coefficient, finite flag, steps APPLIED, steps skipped] - `steps applied` is AdamW's bias-correction step count"""
+        st = self._state
+        return {"steps": self._steps, "flat": None if st is None else st["flat"].detach().clone(),
+                "norm_clip": None if st is None else st["norm_clip"].detach().clone()}
+
+    def load_state_dict(self, sd):
+        """inverse of state_dict(); before the first step the state is kept and applied when the tables are built"""
+        if self._state is None:
+            self._pending_load = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sd.items()}
+            self._steps = int(sd["steps"])
+            return
+        st = self._state
+        self._steps = int(sd["steps"])
+        if sd.get("flat") is not None:
+            if sd["flat"].shape != st["flat"].shape:
+                raise Y3DError(f"optimizer state of shape {tuple(sd['flat'].shape)} does not fit these parameters {tuple(st['flat'].shape)}")
+            st["flat"].copy_(sd["flat"])
+            st["norm_clip"].copy_(sd["norm_clip"])
 
     def set_hyper(self):
         """write the groups' current lr / weight_decay into the EXISTING device tables (in place: a captured hipGraph of the step keeps
@@ -192,10 +218,17 @@ class FusedAdamW(FusedSGD):
         super().__init__(param_groups, lr=lr, momentum=betas[0], nesterov=False, weight_decay=weight_decay)
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
 
+    def step(self, max_norm: float | None = 10.0):
+        """as FusedSGD.step; without a `max_norm` the clipping launch still runs (with an infinite bound: coefficient 1), because the
+        bias corrections read the number of APPLIED steps from its device-side counter - ONE source for the step count, whether or not
+        the step is clipped, eager or replayed from a hipGraph, fresh or resumed (round-3 advisor finding).  Side effect: a step with a
+        non-finite gradient norm is skipped in that case too."""
+        return super().step(max_norm=float("inf") if max_norm is None else max_norm)
+
     def _update(self, L, st, clip, s):
         b1, b2 = self.betas
-        bc1 = 1.0 - b1 ** self._steps
-        bc2s = math.sqrt(1.0 - b2 ** self._steps)
+        bc1 = 1.0 - b1 ** max(self._steps, 1)  # (placeholders: the kernel recomputes both from the device-side step count)
+        bc2s = math.sqrt(1.0 - b2 ** max(self._steps, 1))
         L.mt_adamw(st["pptr"].data_ptr(), st["gptr"].data_ptr(), st["bptr"].data_ptr(), st["bptr2"].data_ptr(), st["sizes"].data_ptr(),
                    st["lr"].data_ptr(), st["wd"].data_ptr(), st["ctensor"].data_ptr(), st["coff"].data_ptr(), st["nchunks"], CHUNK, b1, b2,
                    self.eps, bc1, bc2s, clip, s)
