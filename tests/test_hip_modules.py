@@ -674,11 +674,19 @@ def test_conv_on_channel_slice_views():
 
 
 def test_hip_library_is_the_path():
-    """no silent fallback: CPU tensors must be refused"""
+    """no silent fallback: the kernel wrappers refuse host tensors, a module answers one with a shape (a meta tensor: the reference
+    constructor's stride probe) - never with values"""
+    from yolov10_3d_amd import ops
     y3d.set_compute_dtype(torch.float32)
     mod = M.Conv(16, 16, 3)
+    x = torch.randn(1, 16, 8, 8)
     with pytest.raises(y3d.Y3DError):
-        mod(torch.randn(1, 16, 8, 8))
+        ops.ConvBNActFn.apply(x, mod.conv.weight, mod.bn.weight, mod.bn.bias, None, 0, mod)
+    assert mod(x).device.type == "meta"
+    mod = mod.to(DEV)
+    with pytest.raises(y3d.Y3DError):  # parameters on the device, input on the host
+        ops.ConvBNActFn.apply(x, mod.conv.weight, mod.bn.weight, mod.bn.bias, None, 0, mod)
+    y3d.set_compute_dtype(torch.bfloat16)
 
 
 def test_bf16_tracks_f32_at_scale():

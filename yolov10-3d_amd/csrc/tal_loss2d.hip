@@ -10,9 +10,12 @@ namespace {
 constexpr int RM = 16;  // reg_max
 
 // gt: (B, n, 5) = cls | box xyxy px
-__global__ void gt2d_prep_kernel(const float* __restrict__ gt, float* __restrict__ rec, int B, int n, int nc) {
+__global__ void gt2d_prep_kernel(const float* __restrict__ gt, float* __restrict__ rec, unsigned* __restrict__ pa, unsigned* __restrict__ po, int B,
+                                 int n, int nc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * n) return;
+  pa[i] = 0u;  // the atomicMax accumulators of resolve_kernel, zeroed by a kernel (not hipMemsetAsync: tal_loss3d.hip, gt_prep_kernel)
+  po[i] = 0u;
   const float* g = gt + (long)i * 5;
   float* r = rec + (long)i * GTW;
   r[G_VALID] = (g[1] + g[2] + g[3] + g[4]) > 0.f ? 1.f : 0.f;
@@ -292,8 +295,7 @@ int y3d_tal2d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   unsigned* pa = (unsigned*)(cand + (long)B * n * topk);
   unsigned* po = pa + (long)B * n;
   float* part = (float*)(po + (long)B * n);
-  Y3D_HIP(hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st));
-  hipLaunchKernelGGL(gt2d_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, rec, B, n, nc);
+  hipLaunchKernelGGL(gt2d_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, rec, pa, po, B, n, nc);
   dim3 gm(cdiv(A, 256), B);
   size_t sm = (size_t)n * GTW * sizeof(float);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric2d_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, align, ovl, n, alpha, beta, n_used);

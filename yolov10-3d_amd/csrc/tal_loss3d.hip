@@ -53,9 +53,14 @@ __device__ __forceinline__ void keypoints(float cx, float cy, float dep, float s
 
 // gt: (B, n, 17) = cls | box xyxy px | c2(2) | s2(2) | c3(2) | s3(3) | depth | hbin | hres ; rec: (B, n, GTW)
 __global__ void gt_prep_kernel(const float* __restrict__ gt, const float* __restrict__ calib, const float* __restrict__ mean_sizes,
-                               float* __restrict__ rec, int B, int n, int nc) {
+                               float* __restrict__ rec, unsigned* __restrict__ pa, unsigned* __restrict__ po, int B, int n, int nc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * n) return;
+  // the per-box maxima that resolve_kernel builds with atomicMax start from zero.  Zeroed HERE, by a kernel, not by hipMemsetAsync: inside
+  // a captured hipGraph of the whole training step the memset nodes were seen NOT to take effect on later replays (stale maxima of the
+  // previous replay's other head set, whose scratch shares the address: tools/probe/graph_debug2.py), while kernel nodes always run
+  pa[i] = 0u;
+  po[i] = 0u;
   int b = i / n;
   const float* g = gt + (long)i * 17;
   float* r = rec + (long)i * GTW;
@@ -147,6 +152,10 @@ __global__ __launch_bounds__(256) void metric_kernel(Levels L, const float* __re
 // utils/loss.py:795-810 `preprocess`: ragged per-box rows [batch_idx | cls | xywh in [0,1] | ...] -> (B, cap, width) zero-padded per image
 // in order of appearance, boxes scaled to pixels and converted to xyxy; n_used[0] = min(largest per-image box count, cap), n_used[1] =
 // the largest count itself (device side: the reference sizes the tensor with a host-side counts.max()).  One block per image.
+__global__ void zero_ints_kernel(int* __restrict__ p, int n) {  // (instead of hipMemsetAsync: see gt_prep_kernel)
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void pad_targets_kernel(const float* __restrict__ rows, int nbox, int width, float* __restrict__ out, int cap,
                                                           float sx, float sy, int* __restrict__ n_used) {
   __shared__ int smax[256];
@@ -344,7 +353,7 @@ int y3d_pad_targets(const float* rows, int nbox, int width, int B, int cap, floa
                     void* stream) {
   Y3D_CHECK(B >= 1 && cap >= 1 && width >= 5 && nbox >= 0, "pad_targets: B, cap >= 1, width >= 5 (cls + box + ...)");
   hipStream_t st = (hipStream_t)stream;
-  Y3D_HIP(hipMemsetAsync(n_used, 0, 2 * sizeof(int), st));
+  hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, n_used, 2);
   hipLaunchKernelGGL(pad_targets_kernel, dim3(B), dim3(256), 0, st, rows, nbox, width, out, cap, scale_x, scale_y, n_used);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
@@ -368,8 +377,7 @@ int y3d_tal3d_assign(int dtype, int nl, const void* const* maps, const int64_t* 
   unsigned* pa = (unsigned*)(cand + (long)B * n * topk);
   unsigned* po = pa + (long)B * n;
   float* part = (float*)(po + (long)B * n);
-  Y3D_HIP(hipMemsetAsync(pa, 0, sizeof(unsigned) * 2L * B * n, st));
-  hipLaunchKernelGGL(gt_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, calib, mean_sizes, rec, B, n, nc);
+  hipLaunchKernelGGL(gt_prep_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, st, gt, calib, mean_sizes, rec, pa, po, B, n, nc);
   dim3 gm(cdiv(A, 256), B);
   size_t sm = (size_t)n * GTW * sizeof(float);
   if (dtype == Y3D_BF16) hipLaunchKernelGGL(metric_kernel<bf16_t>, gm, dim3(256), sm, st, L, rec, calib, mean_sizes, align, sim, n, alpha, beta, gamma, n_used, mode);

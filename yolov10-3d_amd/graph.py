@@ -110,6 +110,9 @@ class GraphedTrainStep:
         # copy that a capture does not allow; the optimizer builds its tables; the allocator warms up).  They must not train: parameters,
         # BatchNorm buffers and counters, optimizer state and step counts are snapshotted here and put back (in place: every address
         # stays) before the capture, so constructing a GraphedTrainStep leaves model and optimizer exactly as it found them.
+        for m in model.modules():  # the fused head re-points its branch parameters / BatchNorm buffers at stacked storage on its first
+            if hasattr(m, "restack"):  # forward: do it now, so that the snapshot below holds the tensors the model will keep
+                m.restack()
         with torch.no_grad():
             seen, tensors = set(), []
             for t in list(model.parameters()) + list(model.buffers()):
@@ -154,6 +157,10 @@ class GraphedTrainStep:
             self.loss, self.items = self._body()
         self._gup = st["gup"]  # kept alive: the graph's memcpy node reads its pinned buffer at every replay
         st["gup"], st["gkey"] = None, None
+        # every device table the captured optimizer launches read (sizes, chunk maps, lr / wd, parameter and state pointers): the optimizer
+        # REPLACES them when its active set or a parameter address changes (an eager step in between); the graph keeps reading these
+        self._opt_tables = dict(st)
+        opt._steps = steps0  # the captured Python counted a step that has not run
         # the device words [min(count, cap), true largest per-image count] of the captured pad_targets launches: graph-private static
         # memory, rewritten by every replay; read back after each one so that an image with more boxes than the kernels take is
         # reported as in the eager loop, not trained on silently truncated targets (round-3 advisor finding)

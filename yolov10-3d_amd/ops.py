@@ -264,6 +264,11 @@ class _PackRegistry:
 
     def __init__(self, mode):
         self.mode, self.entries, self.epoch, self.tables = mode, {}, None, None
+        # A hipGraph capture (graph.GraphedTrainStep) bakes in the ADDRESSES of the descriptor tables and of the packed buffers it looked
+        # up: both must outlive the graph.  Tables used while capturing are kept here for good (a later `_pack_all` with more entries -
+        # a second model in the process - builds new tables and would otherwise free the ones the graph's launch still reads: it then
+        # follows whatever "pointers" the reused memory holds), entries looked up while capturing are never evicted.
+        self.captured_tables = []
 
     def _pack_one(self, e):
         L, st = lib(), stream()
@@ -293,6 +298,8 @@ class _PackRegistry:
             self.tables = ((key, dt), torch.tensor(desc, dtype=torch.int64, device=dev), torch.tensor(ct, dtype=torch.int32, device=dev),
                            torch.tensor(co, dtype=torch.int32, device=dev), len(ct))
         _, desc, ct, co, n = self.tables
+        if torch.cuda.is_current_stream_capturing() and not any(t is self.tables for t in self.captured_tables):
+            self.captured_tables.append(self.tables)
         lib().mt_pack_weights(dt, desc.data_ptr(), ct.data_ptr(), co.data_ptr(), n, self.CHUNK, stream())
 
     def lookup(self, w32, src_ptr, geo, dtype, ver=None):
@@ -314,11 +321,14 @@ class _PackRegistry:
             self._pack_one(e)
             return e["dst"]
         e["seen"] = WEIGHT_EPOCH
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            e["pinned"] = True
         if self.epoch != now:
             self.epoch = now
             # (not while a hipGraph is being captured: dropping entries changes the table key, and rebuilding the descriptor tables is a
             # host-to-device copy, which a capture does not allow - entries of a model that is gone wait for the next eager step)
-            stale = [] if torch.cuda.is_current_stream_capturing() else [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > self.KEEP]
+            stale = [] if capturing else [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > self.KEEP and not v.get("pinned")]
             for k in stale:
                 del self.entries[k]
             self._pack_all(geo[5])
@@ -344,6 +354,7 @@ class _QuantRegistry:
 
     def __init__(self):
         self.entries, self.epoch, self.tables = {}, None, None
+        self.captured_tables = []  # as _PackRegistry: tables a hipGraph capture has baked in stay alive
 
     def _run(self, ents):
         dev = ents[0]["weff"].device
@@ -357,6 +368,8 @@ class _QuantRegistry:
                 r += rows
             self.tables = (key, torch.tensor(desc, dtype=torch.int64, device=dev), torch.tensor(rb, dtype=torch.int32, device=dev), len(ents), r)
         _, desc, rb, nt, nrows = self.tables
+        if torch.cuda.is_current_stream_capturing() and not any(t is self.tables for t in self.captured_tables):
+            self.captured_tables.append(self.tables)
         lib().mt_fp8w_quantize(desc.data_ptr(), rb.data_ptr(), nt, nrows, stream())
 
     def lookup(self, w32, ver=None):
@@ -375,10 +388,12 @@ class _QuantRegistry:
             self.tables = tb
             return e["weff"], (WEIGHT_EPOCH, e["count"])
         e["seen"] = WEIGHT_EPOCH
+        if torch.cuda.is_current_stream_capturing():
+            e["pinned"] = True
         if self.epoch != WEIGHT_EPOCH:
             self.epoch = WEIGHT_EPOCH
             if not torch.cuda.is_current_stream_capturing():  # as _PackRegistry.lookup
-                for k in [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > _PackRegistry.KEEP]:
+                for k in [k for k, v in self.entries.items() if WEIGHT_EPOCH - v["seen"] > _PackRegistry.KEEP and not v.get("pinned")]:
                     del self.entries[k]
             self._run(list(self.entries.values()))
             for v in self.entries.values():
