@@ -57,6 +57,21 @@ int y3d_mt_pack_weights(int dtype, const int64_t* desc, const int* chunk_tensor,
 int y3d_mt_fp8w_quantize(const int64_t* desc, const int* row_begin, int ntensors, int nrows, void* stream);
 /* codes (rows, K) + scale (rows) -> fp32 weights (loading a 1-byte-per-weight checkpoint) */
 int y3d_fp8w_dequantize(const uint8_t* codes, const float* scale, float* w, int rows, int K, void* stream);
+/* fp8 MFMA convolution family (conv3x3_fp8.hip; BASELINE configs[4], no reference counterpart): 3x3 stride-1 "same" conv FORWARD on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with OCP-MX operands.
+ *   y3d_fp8_quantize_act: bf16 NHWC rows x (M pixels, row stride xsw elements, C % 32 == 0) -> e4m3 codes q (M, C) + E8M0 block scales s
+ *     (M, C / 32): scale = the smallest power of two with amax(32 channels) / scale <= 448, code = RNE(x / scale) (never saturates);
+ *   y3d_fp8_pack_weight_fwd: the fp8w quantiser's codes (rows, Cg * 9) in OIHW order + power-of-two row scales -> K-contiguous bytes
+ *     wq (rows, 9, Cg) + E8M0 bytes ws (rows);
+ *   y3d_conv3x3_fp8_fwd: y (bf16 NHWC, pixel stride ysw) = conv(x, w) with fp32 accumulation; training form: stat_partials
+ *     [y3d_conv3x3_fp8_stat_rows][Cout][2] (sum, sum^2 of y as stored), eval form: y = act(conv * scale[c] + shift[c]).
+ *     Served geometries: y3d_conv3x3_fp8_ok (Cin / groups a multiple of 64, at least 128; Cout / groups a multiple of 16). */
+int y3d_fp8_quantize_act(const void* x, int64_t xsw, int64_t M, int C, uint8_t* q, uint8_t* s, void* stream);
+int y3d_fp8_pack_weight_fwd(const uint8_t* codes, const float* scale, int rows, int Cg, uint8_t* wq, uint8_t* ws, void* stream);
+int y3d_conv3x3_fp8_ok(int B, int H, int W, int Cin, int Cout, int groups);
+int y3d_conv3x3_fp8_stat_rows(int B, int H, int W);
+int y3d_conv3x3_fp8_fwd(const uint8_t* xq, const uint8_t* xs, int B, int H, int W, int Cin, const uint8_t* wq, const uint8_t* ws, void* y, int64_t ysw,
+                        int Cout, int groups, float* stat_partials, const float* scale, const float* shift, int act, void* stream);
 int y3d_conv_kpad(int dtype, int k_total);
 /* number of BatchNorm partial rows of the generic implicit-GEMM kernel: ceil(B*Ho*Wo / 128) */
 int y3d_conv_stat_blocks(int B, int Ho, int Wo);

@@ -1109,3 +1109,31 @@ def fp8w_state(spec, state):
         else:
             out[k] = v
     return out
+
+
+def mx_quantize_act(x, block=32):
+    """OCP-MX block quantisation of an activation tensor along its channels - the operand format of the fp8 MFMA convolution
+    (yolov10-3d_amd/csrc/conv3x3_fp8.hip: y3d_fp8_quantize_act; no reference counterpart - the reference has no 8-bit path).
+    x (B, C, H, W), C % 32 == 0 -> (codes uint8 (B, C, H, W), scale bytes uint8 (B, C / 32, H, W), x_eff fp32 = value(code) * 2^(byte - 127)).
+    Per (pixel, 32-channel block): scale = the smallest power of two with amax / scale <= 448 (so nothing saturates; 1 for an all-zero
+    block, exponent clamped at -127), code = torch.float8_e4m3fn(x / scale): round to nearest even."""
+    B, C, H, W = x.shape
+    assert C % block == 0
+    xb = x.detach().float().reshape(B, C // block, block, H, W)
+    amax = xb.abs().amax(2, keepdim=True)
+    m, E = torch.frexp(amax)  # amax = m * 2^E, m in [0.5, 1)
+    e = (E - 9 + (m > 0.875).to(E.dtype)).clamp(min=-127)
+    e = torch.where(amax > 0, e, torch.zeros_like(e))
+    inv = torch.exp2(-e.double()).float()
+    q = (xb * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    x_eff = (q.float().double() * torch.exp2(e.double())).float().reshape(B, C, H, W)
+    return q.view(torch.uint8).reshape(B, C, H, W), (e + 127).to(torch.uint8).reshape(B, C // block, H, W), x_eff
+
+
+def conv3x3_fp8(x, w, groups=1):
+    """3x3 stride-1 'same' convolution as the fp8 MFMA path computes it: fp8w-quantised weights (per-output-channel power-of-two
+    scales, fp8w_quantize) x MX block-quantised activations (mx_quantize_act), products exact, accumulation in high precision
+    (float64 here; the kernel: fp32 in its own order).  -> y fp32"""
+    w_eff = fp8w_quantize(w)[2]
+    x_eff = mx_quantize_act(x)[2]
+    return F.conv2d(x_eff.double(), w_eff.double(), None, 1, 1, 1, groups).float()
