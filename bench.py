@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0   # same guide: block-scaled fp8 (v_mfma_scale_f32_16x16x128_f8f6f4), dense
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
@@ -79,8 +80,10 @@ def roofline_key(model, seen, dt_code, B, S):
         mid = head.o2o_heads[0][0][1].conv.in_channels
         k2 = head.o2o_heads[0][0][1].conv.kernel_size[0]
         if k2 == 3 and len({h[0][1].conv.in_channels for h in head.o2o_heads}) == 1:
-            return ("conv_fwd", dt_code, B, S // 8, S // 8, 16 * mid, 16 * mid, 3, 1, 16)
-    cands = [k for k in seen if k[0] == "conv_fwd" and k[7] == 3 and k[8] == 1]
+            key = ("conv_fwd", dt_code, B, S // 8, S // 8, 16 * mid, 16 * mid, 3, 1, 16)
+            f8 = ("conv_fwd_fp8",) + key[1:]  # the same launch on the fp8 MFMA kernel (--weights fp8)
+            return f8 if f8 in seen else key
+    cands = [k for k in seen if k[0] in ("conv_fwd", "conv_fwd_fp8") and k[7] == 3 and k[8] == 1]
     return max(cands, key=lambda k: (conv_key_flops(k), k)) if cands else None
 
 
@@ -155,6 +158,9 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--weights", default="full", choices=["full", "fp8"],
                     help="fp8: conv weights as OCP e4m3 codes with per-output-channel power-of-two scales (BASELINE configs[4]; csrc/fp8w.hip)")
+    ap.add_argument("--fp8-emulate", action="store_true",
+                    help="with --weights fp8: keep every convolution on the bf16 matrix cores (fp8-VALUED weights only: the round-3 form), for A/B runs "
+                         "against the fp8 MFMA convolutions (csrc/conv3x3_fp8.hip) that --weights fp8 turns on by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--infer-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (rehearsal of the N>1 path on one GPU)")
@@ -197,6 +203,7 @@ def main(argv=None):
     y3d.set_compute_dtype(dtype)
     if args.weights == "fp8":
         y3d.set_weight_quant("fp8")
+        y3d.set_fp8_conv(not args.fp8_emulate and dtype == torch.bfloat16)
     torch.manual_seed(0)
     is3d = "3D" in args.model  # the 2D yamls (BASELINE configs[0] / L-2D) run through the same step for profiling
     model = (y3d.YOLOv10_3DDetectionModel if is3d else y3d.YOLOv10DetectionModel)(args.model).to(dev).train()
@@ -402,7 +409,8 @@ def main(argv=None):
             _, _, kB, kH, kW, kCin, kCout, kk, ks, kg = k1_key
             flops = conv_key_flops(k1_key)
             ach = flops / (avg_ms * 1e-3) / 1e12
-            peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+            is_f8 = k1_key[0] == "conv_fwd_fp8"
+            peak = MFMA_FP8_DENSE_PEAK_TFLOPS if is_f8 else (MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS)
             # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the run, so this is the figure of the
             # committed rocprofv3 passes over this same command (tools/pmc_summary.py), labelled with the commit they were taken at
             traffic, traffic_src = None, None
@@ -414,8 +422,9 @@ def main(argv=None):
                 traffic = pm.get("traffic_bytes_per_launch")
                 traffic_src = "profiles/pmc_headline.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s)" % pm.get("commit", "?")
             what = "fused head layer 2" if kg == 16 else "largest 3x3 s1 forward launch of the step"
-            roof = {"bound": "mfma", "kernel": "3x3 s1 conv forward %s (persistent resident-halo implicit GEMM, csrc/conv3x3_wide.hip), %s @%dx%d B=%d (%s)"
-                    % (args.dtype, ("%d groups of %d->%d" % (kg, kCin // kg, kCout // kg)) if kg > 1 else "%d->%d" % (kCin, kCout), kH, kW, kB, what),
+            roof = {"bound": "mfma", "kernel": "3x3 s1 conv forward %s, %s @%dx%d B=%d (%s)"
+                    % ("fp8 e4m3 x e4m3, MX block scales, v_mfma_scale_f32_16x16x128_f8f6f4 (persistent resident-halo kernel, csrc/conv3x3_fp8.hip)" if is_f8
+                       else args.dtype + " (persistent resident-halo implicit GEMM, csrc/conv3x3_wide3.hip)", ("%d groups of %d->%d" % (kg, kCin // kg, kCout // kg)) if kg > 1 else "%d->%d" % (kCin, kCout), kH, kW, kB, what),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_timed": len(res), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops}
         cpu = None
@@ -429,8 +438,8 @@ def main(argv=None):
         out = {
             "metric": "train_images_per_sec", "value": round(best_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * world * B / best_ips, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model}{' (3D head)' if is3d else ' (2D head)'}, {S}x{S}, {args.dtype}{'' if args.weights == 'full' else ' MFMA on fp8 e4m3-VALUED conv weights (weight-format emulation: no fp8 MFMA instruction runs, no speed claim)'}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
+            "vs_baseline": None, "dtype": ("fp8" if y3d.fp8_conv() else args.dtype), "data": "synthetic",
+            "config": {"workload": f"{args.model}{' (3D head)' if is3d else ' (2D head)'}, {S}x{S}, {args.dtype}{'' if args.weights == 'full' else (' + fp8: e4m3 conv weights; the 3x3 stride-1 convolutions the fp8 kernel serves (both head layers) run e4m3 x e4m3 with MX block-scaled activations on v_mfma_scale_f32_16x16x128_f8f6f4 in the forward, bf16 in the backward' if y3d.fp8_conv() else ' MFMA on fp8 e4m3-VALUED conv weights (--fp8-emulate: weight-format emulation, no fp8 MFMA instruction runs)')}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                        "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": args.backend if dist.is_initialized() else None,
             "steps_skipped_nonfinite": int(opt.last_norm[4]) if opt.last_norm is not None else None,

@@ -60,7 +60,8 @@ int y3d_fp8w_dequantize(const uint8_t* codes, const float* scale, float* w, int 
 /* fp8 MFMA convolution family (conv3x3_fp8.hip; BASELINE configs[4], no reference counterpart): 3x3 stride-1 "same" conv FORWARD on
  * v_mfma_scale_f32_16x16x128_f8f6f4 with OCP-MX operands.
  *   y3d_fp8_quantize_act: bf16 NHWC rows x (M pixels, row stride xsw elements, C % 32 == 0) -> e4m3 codes q (M, C) + E8M0 block scales s
- *     (M, C / 32): scale = the smallest power of two with amax(32 channels) / scale <= 448, code = RNE(x / scale) (never saturates);
+ *     (M, y3d_fp8_scale_pitch(C)): C / 32 bytes per pixel, rows padded to whole dwords; scale = the smallest power of two with
+ *     amax(32 channels) / scale <= 448, code = RNE(x / scale) (never saturates);
  *   y3d_fp8_pack_weight_fwd: the fp8w quantiser's codes (rows, Cg * 9) in OIHW order + power-of-two row scales -> K-contiguous bytes
  *     wq (rows, 9, Cg) + E8M0 bytes ws (rows);
  *   y3d_conv3x3_fp8_fwd: y (bf16 NHWC, pixel stride ysw) = conv(x, w) with fp32 accumulation; training form: stat_partials
@@ -70,6 +71,7 @@ int y3d_fp8_quantize_act(const void* x, int64_t xsw, int64_t M, int C, uint8_t* 
 int y3d_fp8_pack_weight_fwd(const uint8_t* codes, const float* scale, int rows, int Cg, uint8_t* wq, uint8_t* ws, void* stream);
 int y3d_conv3x3_fp8_ok(int B, int H, int W, int Cin, int Cout, int groups);
 int y3d_conv3x3_fp8_stat_rows(int B, int H, int W);
+int y3d_fp8_scale_pitch(int C);
 int y3d_conv3x3_fp8_fwd(const uint8_t* xq, const uint8_t* xs, int B, int H, int W, int Cin, const uint8_t* wq, const uint8_t* ws, void* y, int64_t ysw,
                         int Cout, int groups, float* stat_partials, const float* scale, const float* shift, int act, void* stream);
 int y3d_conv_kpad(int dtype, int k_total);
@@ -147,6 +149,10 @@ int y3d_bn_eval_scale(int C, const float* gamma, const float* beta, const float*
 /* u = y*scale+shift (+res if res_mode==2); z = act ? silu(u) : u; (+res if res_mode==1) */
 int y3d_bn_act_fwd(int dtype, const void* y, int64_t ysw, const float* scale, const float* shift, int act, int res_mode,
                    const void* res, int64_t rsw, void* z, int64_t zsw, int64_t P, int C, void* stream);
+/* y3d_bn_act_fwd (bf16, no residual, C % 64 == 0) that ALSO writes the fp8 copy of z the next layer's fp8 MFMA convolution reads:
+ * q (P, C) e4m3 codes + s (P, y3d_fp8_scale_pitch(C)) E8M0 block scales, exactly what y3d_fp8_quantize_act makes of z */
+int y3d_bn_act_fwd_q(const void* y, int64_t ysw, const float* scale, const float* shift, int act, void* z, int64_t zsw, uint8_t* q, uint8_t* s,
+                     int64_t P, int C, void* stream);
 int y3d_bn_bwd_blocks(int64_t P, int C);
 /* pass 1: partials [y3d_bn_bwd_blocks(P, C)][C][2] = (sum g, sum g*xhat), g = dz * act'(u) */
 int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,

@@ -232,9 +232,39 @@ def init_state(spec: dict, seed: int = 0, randomize_bn: bool = True) -> Dict[str
 class Ctx:
     """Execution context: the flat parameter dict and the train/eval switch."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], training: bool):
+    def __init__(self, state: Dict[str, torch.Tensor], training: bool, fp8_conv: bool = False):
         self.st = state
         self.training = training
+        # restate the fp8 MFMA convolution mode (BASELINE configs[4]; yolov10-3d_amd/csrc/conv3x3_fp8.hip, no reference counterpart): the
+        # forward of every 3x3 stride-1 Conv the kernel serves sees its input MX block-quantised (mx_quantize_act); the state is
+        # expected to hold the fp8-valued weights already (fp8w_state); gradients pass straight through (_Fp8ConvSTE)
+        self.fp8_conv = fp8_conv
+
+
+def fp8_conv_served(x, w, s, pad, g):
+    """the geometries y3d_conv3x3_fp8_ok takes: 3x3 stride 1 'same', input channels per group a multiple of 64 and >= 128, output
+    channels per group a multiple of 16"""
+    cin, cout = x.shape[1], w.shape[0]
+    return (w.shape[-1] == 3 and s == 1 and pad == 1 and (cin // g) % 64 == 0 and cin // g >= 128 and (cout // g) % 16 == 0
+            and x.shape[3] >= 8 and x.shape[2] >= 4)
+
+
+class _Fp8ConvSTE(torch.autograd.Function):
+    """forward: conv(mx_quantize_act(x), w); backward: the gradients of conv(x, w) - the data gradient sees w, the weight gradient the
+    UNquantised x (the HIP path keeps both on its bf16 kernels: straight-through)"""
+
+    @staticmethod
+    def forward(ctx, x, w, g):
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return F.conv2d(mx_quantize_act(x)[2].to(x.dtype), w, None, 1, 1, 1, g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, 1, 1, 1, ctx.g) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, 1, 1, 1, ctx.g) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
 
 
 def conv_bn_act(ctx: Ctx, p: str, x, k=1, s=1, g=1, act=True, pad=None):
@@ -243,7 +273,10 @@ def conv_bn_act(ctx: Ctx, p: str, x, k=1, s=1, g=1, act=True, pad=None):
     w = st[p + ".conv.weight"]
     if pad is None:
         pad = w.shape[-1] // 2
-    y = F.conv2d(x, w, None, s, pad, 1, g)
+    if getattr(ctx, "fp8_conv", False) and fp8_conv_served(x, w, s, pad, g):
+        y = _Fp8ConvSTE.apply(x, w, g)
+    else:
+        y = F.conv2d(x, w, None, s, pad, 1, g)
     y = F.batch_norm(y, st[p + ".bn.running_mean"], st[p + ".bn.running_var"], st[p + ".bn.weight"],
                      st[p + ".bn.bias"], ctx.training, BN_MOM, BN_EPS)
     if ctx.training:
@@ -529,8 +562,8 @@ def model_strides(spec):
     raise ValueError("no detect layer")
 
 
-def forward(spec, state, img, training: bool):
-    ctx = Ctx(state, training)
+def forward(spec, state, img, training: bool, fp8_conv: bool = False):
+    ctx = Ctx(state, training, fp8_conv)
     strides = model_strides(spec)
     saved = {}
     x = img

@@ -21,7 +21,7 @@ def quantize_act(x_nchw_bf16):
     xin = ops.to_nhwc(x_nchw_bf16, torch.bfloat16, dense=True)
     B, C, H, W = xin.shape
     q = torch.empty(B, H, W, C, dtype=torch.uint8, device=xin.device)
-    s = torch.empty(B, H, W, C // 32, dtype=torch.uint8, device=xin.device)
+    s = torch.zeros(B, H, W, ops.lib().fp8_scale_pitch(C), dtype=torch.uint8, device=xin.device)
     ops.lib().fp8_quantize_act(xin.data_ptr(), xin.stride(3), B * H * W, C, q.data_ptr(), s.data_ptr(), ops.stream())
     return q, s
 
@@ -75,11 +75,12 @@ def test_fp8_act_quantizer_bit_exact_vs_oracle(shape):
     x = x.to(torch.bfloat16)
     q, s = quantize_act(x.to(DEV))
     cq, cs, _ = RS.mx_quantize_act(x.float())
-    assert torch.equal(s.cpu().permute(0, 3, 1, 2), cs), "E8M0 scale bytes differ"
+    assert torch.equal(s.cpu()[..., : C // 32].permute(0, 3, 1, 2), cs), "E8M0 scale bytes differ"
     assert torch.equal(q.cpu().permute(0, 3, 1, 2), cq), "e4m3 codes differ"
 
 
 CONV_CASES = [  # B, Cin, Cout, groups, H, W
+    (2, 320, 256, 1, 16, 24), (1, 384, 96, 2, 8, 16),
     (4, 128, 128, 1, 8, 16), (5, 128, 256, 1, 16, 16), (2, 256, 128, 2, 20, 20), (3, 1024, 1024, 8, 12, 40), (1, 384, 96, 2, 9, 23),
     (9, 2048, 2048, 16, 8, 16), (2, 128, 2048, 1, 24, 24),
 ]
@@ -143,3 +144,89 @@ def test_fp8_conv_affine_epilogue_matches_training_form():
     want = torch.nn.functional.silu(raw.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     tol = 2.0 ** -7 * (raw.float().abs() * sc.view(1, -1, 1, 1) + 1.0)
     assert bool(((out.float() - want).abs() <= tol).all())
+
+
+def _head_case(dev):
+    """v10Detect3d, two levels of 128 / 256 channels, 128-wide branches (the S / X head geometry the fp8 kernel serves), B = 3"""
+    from yolov10_3d_amd import modules as M
+    torch.manual_seed(5)
+    chan = {k + "_c": 128 for k in ("cls", "o2d", "s2d", "o3d", "s3d", "hd", "dep", "dep_un")}
+    hd = M.v10Detect3d(3, (128, 256), False, chan, False, True, False, False, 2, False, False, 3, 3)
+    hd.stride = torch.tensor([8.0, 16.0])
+    hd.bias_init()
+    for b in hd.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.weight.data.uniform_(0.5, 1.5)
+            b.bias.data.normal_(0, 0.2)
+    xs = [torch.nn.functional.silu(torch.randn(3, 128, 24, 16)), torch.nn.functional.silu(torch.randn(3, 256, 12, 8))]
+    return hd, xs
+
+
+def _oracle_head(state, xs, fp8_conv):
+    """the oracle's dense head forward (both head sets) on `state` with / without the fp8 convolution mode; -> (maps, input grads, grads)"""
+    L = {"nl": 2, "k1": 3, "k2": 3, "nc": 3}
+    st = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in state.items()}
+    xin = [x.clone().requires_grad_(True) for x in xs]
+    ctx = RS.Ctx(st, True, fp8_conv)
+    o2o, _ = RS.head3d_dense(ctx, "h", "o2o_heads", [x.detach() for x in xin], L)
+    o2m, _ = RS.head3d_dense(ctx, "h", "o2m_heads", xin, L)
+    torch.manual_seed(9)
+    wts = [torch.randn_like(t) for t in o2m + o2o]
+    sum((t * w).sum() for t, w in zip(o2m + o2o, wts)).backward()
+    return o2m + o2o, [x.grad for x in xin], {k: v.grad for k, v in st.items() if v.requires_grad and v.grad is not None}, wts
+
+
+def test_fp8_conv_head_training_step_vs_oracle():
+    """the whole 3D head (layer 1: Cin -> 16 x 128 stacked, layer 2: 16 groups of 128 -> 128, projections) with fp8 weights AND fp8
+    MFMA convolutions against the oracle with the same mode restated (fp8w_state weights, MX-quantised conv inputs, straight-through
+    gradients).  Quantisation is discontinuous: the bf16 rounding noise of an activation (2^-9) moves ~1 code in 32 across an e4m3
+    rounding boundary, a full 2^-3 step each, so the HIP path (bf16 activations) and the oracle (fp32 activations) differ by about the
+    FORMAT's own noise whatever the kernel does - the arithmetic itself is pinned bit for bit by the kernel-level tests above.
+    Stated bound: dist(HIP fp8, oracle fp8) <= 1.5 x dist(oracle fp8, oracle bf16-activation) + dist(HIP bf16, oracle bf16) in relative
+    L2 for head maps, input gradients and weight gradients, and the HIP fp8 path differs from the HIP bf16 path by 0.5 .. 2 x the
+    format noise the oracle shows (the mode is on, and is the mode the oracle restates)."""
+    import copy
+    from test_hip_modules import l2_rel
+    hd, xs = _head_case(DEV)
+    xs = [x.to(torch.bfloat16).float() for x in xs]  # both sides start from the same bf16 level maps
+    state = {"h." + k: v.clone() for k, v in hd.state_dict().items()}
+    stq = {k: (RS.fp8w_quantize(v)[2] if (k.endswith(".conv.weight") and v.dim() == 4) else v) for k, v in state.items()}
+    ref = {m: _oracle_head(stq, xs, m) for m in (False, True)}
+    res = {}
+    y3d.set_compute_dtype(torch.bfloat16)
+    y3d.set_weight_quant("fp8")
+    try:
+        for mode in (False, True):
+            y3d.set_fp8_conv(mode)
+            m = copy.deepcopy(hd).to(DEV).train()
+            xin = [x.to(DEV).requires_grad_(True) for x in xs]
+            seen = []
+            ops.TIMER = ops.KernelTimer(lambda key: seen.append(key[0]) or False)
+            out = m(xin)
+            ops.TIMER = None
+            maps = out["one2many"] + out["one2one"]
+            sum((t.float() * w.to(DEV)).sum() for t, w in zip(maps, ref[mode][3])).backward()
+            torch.cuda.synchronize()
+            assert ("conv_fwd_fp8" in seen) == mode, f"fp8 kernel launches: {seen.count('conv_fwd_fp8')} (mode {mode})"
+            if mode:
+                assert seen.count("conv_fwd_fp8") == 4 and "conv_fwd" not in seen  # two levels x (layer 1, layer 2)
+            named = dict(m.named_parameters())
+            grads = {k: named[k[2:]].grad for k in ref[mode][2] if k[2:] in named and named[k[2:]].grad is not None and k.endswith("conv.weight")}
+            res[mode] = (maps, [x.grad for x in xin], grads)
+    finally:
+        y3d.set_fp8_conv(False)
+        y3d.set_weight_quant(None)
+    dist = {}
+    for mode in (False, True):
+        maps, dxs, grads = res[mode]
+        rm, rdx, rg, _ = ref[mode]
+        dist[mode] = (max(l2_rel(a, b) for a, b in zip(maps, rm)), max(l2_rel(a, b) for a, b in zip(dxs, rdx)),
+                      max(l2_rel(v, rg[k]) for k, v in grads.items()))
+    fmt = (max(l2_rel(a, b) for a, b in zip(ref[True][0], ref[False][0])), max(l2_rel(a, b) for a, b in zip(ref[True][1], ref[False][1])),
+           max(l2_rel(ref[True][2][k], ref[False][2][k]) for k in res[True][2]))
+    hip_fmt = max(l2_rel(a, b) for a, b in zip(res[True][0], res[False][0]))
+    print(f"HIP vs oracle, relative L2 (maps, dx, dW): bf16 activations {dist[False]}, fp8 convolutions {dist[True]}; format noise (oracle fp8 vs oracle bf16) {fmt}; "
+          f"HIP fp8 vs HIP bf16 maps {hip_fmt:.3e}")
+    for a, b, f, what in zip(dist[True], dist[False], fmt, ("head maps", "input gradients", "weight gradients")):
+        assert a <= 1.5 * f + b, f"{what}: fp8 path {a:.3e} from its oracle, format noise {f:.3e}, bf16 path {b:.3e} from its own"
+    assert 0.5 * fmt[0] <= hip_fmt <= 2 * fmt[0] and 1e-3 < fmt[0] < 0.15

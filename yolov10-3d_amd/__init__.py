@@ -8,7 +8,7 @@
 HIP kernels: csrc/*.hip behind the C ABI of include/y3d.h (liby3d_hip.so, bound by _lib.py).
 """
 from yolov10_3d_amd._lib import LIB_PATH, Y3DError, lib  # noqa: F401
-from yolov10_3d_amd.ops import compute_dtype, set_compute_dtype, set_weight_quant, weight_quant  # noqa: F401
+from yolov10_3d_amd.ops import compute_dtype, fp8_conv, set_compute_dtype, set_fp8_conv, set_weight_quant, weight_quant  # noqa: F401
 from yolov10_3d_amd import modules, tasks, loss, kitti  # noqa: F401
 from yolov10_3d_amd.tasks import (DetectionModel, YOLOv10DetectionModel, YOLOv10_3DDetectionModel, parse_model,  # noqa: F401
                                   yaml_model_load)

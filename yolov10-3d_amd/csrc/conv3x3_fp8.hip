@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fp8_common.h"
 
 namespace {
 
@@ -502,23 +503,9 @@ int launch_f8(const F8P& p, hipStream_t st) {
 
 // ---- activation quantiser: bf16 NHWC (pixel-dense, pixel stride xsw elements) -> e4m3 codes [M][C] + E8M0 block scales [M][C / 32] -------
 // One thread per 8 channels (16 bytes in, 8 out); the four threads of a 32-channel block fold their maxima with two quad-permute DPP ops.
-__device__ __forceinline__ float quad_max(float v) {
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
-  return v;
-}
-
-// E8M0 byte of the smallest power of two s with amax / s <= 448 (448 = 1.75 * 2^8); amax == 0 -> 127 (s = 1)
-__device__ __forceinline__ int mx_scale_byte(float amax) {
-  const unsigned bits = __float_as_uint(amax);
-  if ((bits & 0x7fffffffu) == 0) return 127;
-  int e = (int)((bits >> 23) & 255) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);  // biased: (E + 127) - 8 (+1 when the mantissa exceeds 1.75)
-  return e < 0 ? 0 : (e > 254 ? 254 : e);
-}
-
 __global__ __launch_bounds__(256) void fp8_act_quant_kernel(const bf16_t* __restrict__ x, long xsw, unsigned char* __restrict__ q, unsigned char* __restrict__ s,
                                                             long M, int C) {
-  const int cpr = C >> 3;
+  const int cpr = C >> 3, SP = fp8_scale_pitch(C);
   const long total = M * cpr;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ((total + 255) & ~255L); i += (long)gridDim.x * 256) {
     const bool live = i < total;
@@ -528,26 +515,11 @@ __global__ __launch_bounds__(256) void fp8_act_quant_kernel(const bf16_t* __rest
     uint4 u = make_uint4(0, 0, 0, 0);
     if (live) u = *(const uint4*)(x + pix * xsw + ch * 8);
     Chunk<bf16_t>::unpack(u, f);
-    float amax = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(f[k]));
-    amax = quad_max(amax);
-    const int sbyte = mx_scale_byte(amax);
-    const float inv = __uint_as_float((unsigned)(254 - sbyte) << 23);  // 2^-(sbyte - 127); sbyte <= 254 keeps it a normal number (sbyte == 254: 2^-127 is
-    // denormal - the product then underflows to the smallest codes, which is what a value that large deserves)
-    unsigned lo = 0, hi = 0;
-    {
-      float g[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) g[k] = fminf(fmaxf(f[k] * inv, -448.f), 448.f);
-      lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(g[0], g[1], 0, false);
-      lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(g[2], g[3], (int)lo, true);
-      hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(g[4], g[5], 0, false);
-      hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(g[6], g[7], (int)hi, true);
-    }
+    unsigned lo, hi;
+    const int sbyte = mx_quantize8(f, lo, hi);
     if (live) {
       *(uint2*)(q + pix * C + ch * 8) = make_uint2(lo, hi);
-      if ((ch & 3) == 0) s[pix * (C >> 5) + (ch >> 2)] = (unsigned char)sbyte;
+      if ((ch & 3) == 0) s[pix * SP + (ch >> 2)] = (unsigned char)sbyte;
     }
   }
 }
@@ -591,11 +563,12 @@ int y3d_fp8_pack_weight_fwd(const uint8_t* codes, const float* scale, int rows, 
 int y3d_conv3x3_fp8_ok(int B, int H, int W, int Cin, int Cout, int groups) {
   if (groups < 1 || Cin % groups || Cout % groups) return 0;
   const int Cg = Cin / groups, Cn = Cout / groups;
-  // Cin % 128: the scale bytes of a pixel are fetched as aligned dwords (4 blocks of 32 channels)
-  return Cg % 64 == 0 && Cg >= 128 && Cin % 128 == 0 && Cn % 16 == 0 && W >= 8 && H >= 4 && B >= 1;
+  return Cg % 64 == 0 && Cg >= 128 && Cn % 16 == 0 && W >= 8 && H >= 4 && B >= 1;
 }
 
 int y3d_conv3x3_fp8_stat_rows(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
+
+int y3d_fp8_scale_pitch(int C) { return fp8_scale_pitch(C); }
 
 int y3d_conv3x3_fp8_fwd(const uint8_t* xq, const uint8_t* xs, int B, int H, int W, int Cin, const uint8_t* wq, const uint8_t* ws, void* y, int64_t ysw,
                         int Cout, int groups, float* stat_partials, const float* scale, const float* shift, int act, void* stream) {
@@ -604,7 +577,7 @@ int y3d_conv3x3_fp8_fwd(const uint8_t* xq, const uint8_t* xs, int B, int H, int 
   Y3D_CHECK((scale == nullptr) == (shift == nullptr) && !(scale && stat_partials), "conv3x3_fp8_fwd: either BatchNorm partials (training) or the affine epilogue (eval)");
   F8P p;
   p.x = xq; p.xs = xs; p.w = wq; p.ws = ws; p.y = (bf16_t*)y; p.part = stat_partials; p.scale = scale; p.shift = shift; p.act = act;
-  p.xsw = Cin; p.xsh = (long)W * Cin; p.xsb = (long)H * W * Cin; p.ysw = ysw; p.CS = Cin / 32;
+  p.xsw = Cin; p.xsh = (long)W * Cin; p.xsb = (long)H * W * Cin; p.ysw = ysw; p.CS = fp8_scale_pitch(Cin);
   p.B = B; p.H = H; p.W = W; p.G = groups; p.Cg = Cin / groups; p.Cn = Cout / groups; p.Ktot = 9 * p.Cg;
   p.ntx = cdiv(W, 16); p.nty = cdiv(H, 8); p.ntc = cdiv(p.Cn, 128); p.nbt = cdiv(B, 4);
   const unsigned long xb = (unsigned long)B * H * W * Cin, wb = (unsigned long)Cout * p.Ktot, sb = (unsigned long)B * H * W * p.CS;

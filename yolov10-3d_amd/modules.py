@@ -546,7 +546,8 @@ class v10Detect3d(nn.Module):
         for i in range(self.nl):
             branches, mids, s1, s2, parts, pos = self._stacks(i)
             half = sum(mids[:8])
-            z1 = ops.FusedConvBNActFn.apply(x[i], s1, 1, (half, sum(mids)), *s1.params())
+            with ops.want_fp8_copy():  # fp8 convolutions on: layer 1's BatchNorm + SiLU pass also writes the fp8 copy layer 2 reads
+                z1 = ops.FusedConvBNActFn.apply(x[i], s1, 1, (half, sum(mids)), *s1.params())
             offs = [sum(mids[:j]) for j in range(16)]
             if s2 is not None and mids[0] % 64 == 0 and getattr(self, "fuse_bn_proj", True):
                 # grouped conv + BatchNorm statistics + projections with BatchNorm/SiLU applied on the fly (no activation tensor)

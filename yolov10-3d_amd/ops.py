@@ -156,6 +156,7 @@ def reset_placement():
     _PLACE_FINAL = None
     _CONCAT_BASE.clear()
     _GRAD_SLOT.clear()
+    _FP8_ACT.clear()
 
 
 def out_tensor(B, C, H, W, dtype, device):
@@ -377,12 +378,14 @@ class _QuantRegistry:
         rows, K = w32.shape[0], w32[0].numel()
         key = (w32.data_ptr(), rows, K)
         e = self.entries.get(key)
+        self.last = e  # (the entry of the weight just looked up: the fp8 MFMA path packs its codes, fp8_weight)
         if e is None:
             dev = w32.device
             e = {"src": w32.data_ptr(), "shape": (rows, K), "keep": w32, "weff": torch.empty(w32.shape, dtype=torch.float32, device=dev),
                  "codes": torch.empty((rows, K), dtype=torch.uint8, device=dev), "scale": torch.empty(rows, dtype=torch.float32, device=dev),
                  "ver": ver, "count": 0, "seen": WEIGHT_EPOCH}
             self.entries[key] = e
+            self.last = e
             tb, self.tables = self.tables, None
             self._run([e])
             self.tables = tb
@@ -424,6 +427,71 @@ def set_weight_quant(mode):
 
 def weight_quant():
     return WEIGHT_QUANT
+
+
+# ---- fp8 MFMA convolutions (csrc/conv3x3_fp8.hip; BASELINE configs[4]) ------------------------------------------------------------
+# With `set_weight_quant("fp8")` AND `set_fp8_conv(True)` the forward of every bf16 3x3 stride-1 Conv whose geometry the kernel serves
+# (y3d_conv3x3_fp8_ok: the head's two 3x3 layers at the S / B / L / X widths) runs on v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 weight
+# codes (the fp8w quantiser's) x e4m3 activations with one E8M0 scale per (pixel, 32 channels).  The activation's fp8 copy comes from its
+# producer when that is a BatchNorm + SiLU pass told to write one (`want_fp8_copy`: y3d_bn_act_fwd_q), else from y3d_fp8_quantize_act.
+# Data and weight gradients stay on the bf16 kernels (x and w_eff in bf16: straight-through).
+FP8_CONV = False
+_FP8_WANT = False
+_FP8_ACT = {}  # address of a bf16 activation -> (q, s, shape, z): the fp8 copy its producer wrote; dropped at the next forward
+
+
+def set_fp8_conv(on: bool):
+    global FP8_CONV
+    if on and WEIGHT_QUANT != "fp8":
+        raise ValueError('set_fp8_conv(True) needs set_weight_quant("fp8"): the kernel multiplies the fp8w quantiser\'s codes')
+    FP8_CONV = bool(on)
+    bump_param_epoch()
+
+
+def fp8_conv():
+    return FP8_CONV
+
+
+class want_fp8_copy:
+    """`with want_fp8_copy(): z = conv_bn_act(...)`: the BatchNorm + SiLU pass inside also writes the fp8 copy of z (when fp8 convolutions
+    are on and the tensor qualifies); the next fp8 convolution that takes z as its input picks it up"""
+
+    def __enter__(self):
+        global _FP8_WANT
+        self.prev, _FP8_WANT = _FP8_WANT, FP8_CONV
+        return self
+
+    def __exit__(self, *a):
+        global _FP8_WANT
+        _FP8_WANT = self.prev
+
+
+def fp8_input(xin):
+    """(q (B, H, W, C) e4m3 codes, s (B, H, W, C / 32) E8M0 bytes) of the bf16 NHWC activation `xin`: the producer's copy, or a quantising pass"""
+    B, C, H, W = xin.shape
+    ent = _FP8_ACT.pop(xin.data_ptr(), None)
+    if ent is not None and ent[2] == (B, C, H, W):
+        return ent[0], ent[1]
+    if not px_dense(xin):
+        xin = to_nhwc(xin, torch.bfloat16, dense=True).contiguous(memory_format=torch.channels_last)
+    q = torch.empty(B, H, W, C, dtype=torch.uint8, device=xin.device)
+    s = torch.empty(B, H, W, lib().fp8_scale_pitch(C), dtype=torch.uint8, device=xin.device)
+    lib().fp8_quantize_act(xin.data_ptr(), xin.stride(3), B * H * W, C, q.data_ptr(), s.data_ptr(), stream())
+    return q, s
+
+
+def fp8_weight(ent, Cg):
+    """(wq (rows, 9, Cg) bytes, ws (rows,) E8M0 bytes) of a quantised 3x3 weight (a _QuantRegistry entry), repacked when its codes changed"""
+    tok = (WEIGHT_EPOCH, ent["count"])
+    hit = ent.get("wq")
+    if hit is None or hit[0] != tok:
+        rows = ent["shape"][0]
+        dev = ent["codes"].device
+        wq = hit[1] if hit is not None else torch.empty(rows, 9, Cg, dtype=torch.uint8, device=dev)
+        ws = hit[2] if hit is not None else torch.empty(rows, dtype=torch.uint8, device=dev)
+        lib().fp8_pack_weight_fwd(ent["codes"].data_ptr(), ent["scale"].data_ptr(), rows, Cg, wq.data_ptr(), ws.data_ptr(), stream())
+        hit = ent["wq"] = (tok, wq, ws)
+    return hit[1], hit[2]
 PROJ_BN_MFMA = not os.environ.get("Y3D_NO_PROJ_BN_MFMA")  # A/B switch: BatchNorm backward of the second head layer recomputing dz on MFMA
 STEM_FUSED = not os.environ.get("Y3D_NO_STEM_FUSED")  # A/B switch: eval stem as im2col + dense conv (the training form) instead of one pass
 PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv packing launches instead of the registry
@@ -501,9 +569,11 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     st = stream()
     dev = x.device
     B, Cin, H, W = x.shape
+    qent = None
     if WEIGHT_QUANT and quant and not (g > 1 and g == Cin and g == w32.shape[0]):
         # fp8w mode: the kernels pack and multiply the fp8-valued shadow of the weight; the master keeps receiving the gradient
         w32, qtok = QUANT.lookup(w32, ver[0] if ver is not None else None)
+        qent = QUANT.last
         ver = ((qtok,), (qtok,) + (ver[1] if ver is not None else (g32._version, b32._version, rm._version, rv._version)))
     Cout, Cg_w, kh, kw = w32.shape
     assert kh == k and kw == k and Cin // g == Cg_w, "Conv: weight shape does not match input"
@@ -593,14 +663,30 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     elif pre_conv is not None:  # the caller has run the conv (fused training stem): pre-BN tensor + BatchNorm partial rows
         y, part, nblk = pre_conv
     else:
-        nblk = L.conv2d_stat_rows(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)
+        # fp8 MFMA forward (set_fp8_conv): e4m3 codes of the weight x the MX-quantised activation; everything after the conv - BatchNorm
+        # statistics from the partial rows, the apply pass, the bf16 backward over (xin, w_eff) - is the bf16 path's
+        f8 = (FP8_CONV and qent is not None and dtype == torch.bfloat16 and k == 3 and s == 1 and p == 1 and Cin_k == Cin
+              and bool(L.conv3x3_fp8_ok(B, H, W, Cin, Cout, g)))
+        nblk = L.conv3x3_fp8_stat_rows(B, H, W) if f8 else L.conv2d_stat_rows(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)
         if training:
             part = _f32(nblk * Cout * 2, dev)
         Cg_pad = Cin_k // g
         ss_eval = None
         if not training:
             wp, ss_eval = _eval_consts(cache, "dense", w32, g32, b32, rm, rv, ver, dtype, k, g, Cin // g, Cg_pad, Cout, eps)
-        if not training and not res_mode:
+        if f8:
+            xq, xs = fp8_input(xin)
+            wq, ws = fp8_weight(qent, Cin // g)
+            if not training and not res_mode:
+                ye = out_tensor(B, Cout, Ho, Wo, dtype, dev)
+                _timed(("conv_eval_fp8", dt, B, H, W, Cin_k, Cout, k, s, g, p),
+                       lambda: L.conv3x3_fp8_fwd(xq.data_ptr(), xs.data_ptr(), B, H, W, Cin, wq.data_ptr(), ws.data_ptr(), ye.data_ptr(), ye.stride(3), Cout, g, None,
+                                                 ss_eval[0].data_ptr(), ss_eval[1].data_ptr(), int(act), st))
+                return ye, None, None
+            _timed(("conv_fwd_fp8", dt, B, H, W, Cin_k, Cout, k, s, g),
+                   lambda: L.conv3x3_fp8_fwd(xq.data_ptr(), xs.data_ptr(), B, H, W, Cin, wq.data_ptr(), ws.data_ptr(), y.data_ptr(), y.stride(3), Cout, g,
+                                             part.data_ptr() if training else None, None, None, 0, st))
+        elif not training and not res_mode:
             # eval: BatchNorm (running statistics) + SiLU folded into the conv epilogue - one launch, no pre-BN tensor; the packed
             # weights and the scale/shift pair are cached until a parameter / buffer is modified in place or re-pointed
             ye = out_tensor(B, Cout, Ho, Wo, dtype, dev)  # a pending placement (C2f / SPPF / Concat slot) is honoured in eval too
@@ -608,7 +694,9 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
                    lambda: L.conv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss_eval[0].data_ptr(), ss_eval[1].data_ptr(),
                                                int(act), ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st))
             return ye, None, None
-        if (not training and res_mode == 1 and dtype == torch.bfloat16
+        if f8:
+            pass
+        elif (not training and res_mode == 1 and dtype == torch.bfloat16
                 and L.conv2d_fwd_affine_res_ok(dt, B, H, W, Cin_k, Cout, g, k, k, s, p)):
             # eval Bottleneck shortcut: conv + folded BatchNorm + SiLU + residual in ONE launch (the narrow resident-weight kernel)
             rr = to_nhwc(res, dtype, dense=True)
@@ -616,16 +704,19 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
             L.conv2d_fwd_affine_res(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), ss_eval[0].data_ptr(), ss_eval[1].data_ptr(), int(act),
                                     rr.data_ptr(), rr.stride(3), ye.data_ptr(), ye.stride(3), Ho, Wo, Cout, g, k, k, s, p, st)
             return ye, None, None
-        if not training:
+        if f8:
+            pass  # the conv ran above
+        elif not training:
             pass  # eval with a residual: conv (cached packed weights) + one BatchNorm / SiLU / residual pass below
         elif pack_cache and training and PACK_CACHE:
             wp = PACK_FWD.lookup(w32, w32.data_ptr(), (Cout, Cin // g, Cg_pad, k * k, k * k * Cg_pad, dt), dtype, ver[0] if ver is not None else None)
         else:
             wp = torch.empty(Cout * k * k * Cg_pad, dtype=dtype, device=dev)
             L.pack_weight_fwd(dt, w32.data_ptr(), wp.data_ptr(), Cout, Cin // g, Cg_pad, k, k, st)
-        _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
-               lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
-                                    k, k, s, p, part.data_ptr() if training else None, st))
+        if not f8:
+            _timed(("conv_fwd", dt, B, H, W, Cin_k, Cout, k, s, g),
+                   lambda: L.conv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin_k, wp.data_ptr(), None, y.data_ptr(), Cout, Ho, Wo, Cout, g,
+                                        k, k, s, p, part.data_ptr() if training else None, st))
     if training:
         stats = _f32(6 * Cout, dev).view(6, Cout)  # mean, invstd, scale, shift, mean_g, mean_gx
         bump_param_epoch()  # bn_finalize updates the running statistics in place
@@ -645,8 +736,15 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
         rr = to_nhwc(res, dtype, dense=True)
         assert rr.shape == z.shape, "residual shape mismatch"
     sc_t, sh_t = (stats[2], stats[3]) if training else (ss_eval[0], ss_eval[1])
-    L.bn_act_fwd(dt, y.data_ptr(), Cout, sc_t.data_ptr(), sh_t.data_ptr(), int(act), res_mode,
-                 rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), z.stride(3), M, Cout, st)
+    if _FP8_WANT and dtype == torch.bfloat16 and not res_mode and Cout % 64 == 0 and not dw:
+        # the consumer is an fp8 MFMA convolution: this pass also writes z's fp8 copy (e4m3 codes + E8M0 block scales)
+        zq = torch.empty(B, Ho, Wo, Cout, dtype=torch.uint8, device=dev)
+        zs = torch.empty(B, Ho, Wo, L.fp8_scale_pitch(Cout), dtype=torch.uint8, device=dev)
+        L.bn_act_fwd_q(y.data_ptr(), Cout, sc_t.data_ptr(), sh_t.data_ptr(), int(act), z.data_ptr(), z.stride(3), zq.data_ptr(), zs.data_ptr(), M, Cout, st)
+        _FP8_ACT[z.data_ptr()] = (zq, zs, (B, Cout, Ho, Wo), z)
+    else:
+        L.bn_act_fwd(dt, y.data_ptr(), Cout, sc_t.data_ptr(), sh_t.data_ptr(), int(act), res_mode,
+                     rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0, z.data_ptr(), z.stride(3), M, Cout, st)
     # [17]: version token of the weights as packed (stacked views / fp8 shadows carry their identity outside the tensor's own counter)
     cfg = (B, Cin, Cin_k, H, W, Cout, Ho, Wo, k, s, p, g, dw, res_mode, training, dtype, int(act), ver[0] if ver is not None else None)
     return z, cfg, (xin, w32, y, stats, rr if res_mode == 2 else None)
