@@ -60,8 +60,8 @@ def test_no_cpu_fallback():
 
 def test_no_kernel_needs_scratch():
     """Every HIP kernel of the library compiles without scratch (register spills / run-time indexed private arrays).  In the LDS-DMA
-    pipelines (conv3x3_wide, conv3x3_wgrad_tile, conv3x3_tile) a scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the
-    prefetch of the next tile (conv3x3_wide.hip header).  The numbers are the compiler's own resource report
+    pipelines (conv3x3_wide3, conv3x3_fp8, conv3x3_wgrad_tile, conv3x3_tile) a scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the
+    prefetch of the next tile (conv3x3_wide3.hip header).  The numbers are the compiler's own resource report
     (`-Rpass-analysis=kernel-resource-usage`), recorded by csrc/build.py at every compile."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("y3d_build", os.path.join(ROOT, "yolov10-3d_amd", "csrc", "build.py"))
@@ -81,5 +81,8 @@ def test_no_kernel_needs_scratch():
     assert n >= 150, f"only {n} kernels reported"
     assert not bad, f"kernels with scratch: {bad}"
     # the headline kernel keeps its two-waves-per-SIMD register budget
-    wide = {k: v for k, v in usage["conv3x3_wide.hip"].items() if "conv3x3_wide_kernel" in k}
+    wide = {k: v for k, v in usage["conv3x3_wide3.hip"].items() if "conv3x3_wide3_kernel" in k}
     assert len(wide) == 4 and all(v["vgprs"] <= 256 for v in wide.values()), wide
+    # ... and the fp8 MFMA kernel (245 registers with the accumulators tied through inline asm; the builtin form spilled 900 dwords)
+    f8 = {k: v for k, v in usage["conv3x3_fp8.hip"].items() if "conv3x3_fp8_kernel" in k}
+    assert len(f8) == 2 and all(v["vgprs"] <= 256 and v["scratch"] == 0 for v in f8.values()), f8

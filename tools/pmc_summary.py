@@ -25,7 +25,7 @@ def load(d, name):
 
 KB = 1024.0
 fd, wd, out = sys.argv[1:4]
-hl = sys.argv[4] if len(sys.argv) > 4 else "conv3x3_wide_kernel<16, 0>"
+hl = sys.argv[4] if len(sys.argv) > 4 else "conv3x3_wide3_kernel<16, 0>"
 hg = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 rows = []

@@ -6,7 +6,7 @@ Reads rocprofv3's `*kernel_trace.csv` (one row per dispatch).  Two tables:
   1. by kernel name (what `--stats` prints), per training step;
   2. by (kernel name, grid size, launch slot): the k-th dispatch of a kernel inside a step always has the same shape (the step is a
      fixed launch sequence), so dispatch index modulo launches-per-step isolates ONE call site.  Persistent kernels use one grid size
-     for every shape (conv3x3_wide: one workgroup per CU) — without the slot the 16 launches per step of `conv3x3_wide_kernel<16, 0>`
+     for every shape (conv3x3_wide: one workgroup per CU) — without the slot the 16 launches per step of `conv3x3_wide3_kernel<16, 0>`
      average into one meaningless row.  The slowest slot of that kernel is the roofline launch of bench.py
      (fused head layer 2 at P3, 966 GFLOP); its average here must agree with bench.py's live HIP-event figure.
 Falls back to `*kernel_stats.csv` (table 1 only) when the trace is absent."""
@@ -80,10 +80,10 @@ def main():
     for avg, name, grid, s, per, lo, hi, n in slots[:top]:
         slot = f"slot {s:3d}/{per:<3d}" if s >= 0 else "unsynchronised"
         print(f"{avg / 1e3:9.1f}us  min {lo / 1e3:9.1f}  max {hi / 1e3:9.1f}  n={n:3d}  grid={grid:9d}  {slot}  {name[:90]}")
-    wide = [x for x in slots if "conv3x3_wide_kernel<16, 0>" in x[1] and x[3] >= 0]
+    wide = [x for x in slots if "conv3x3_wide3_kernel<16, 0>" in x[1] and x[3] >= 0]
     if wide:
         avg, name, grid, s, per, lo, hi, n = wide[0]
-        print(f"# headline launch (slowest slot of conv3x3_wide_kernel<16, 0>, the fused head layer-2 forward at P3): avg {avg / 1e3:.1f} us over {n} launches"
+        print(f"# headline launch (slowest slot of conv3x3_wide3_kernel<16, 0>, the fused head layer-2 forward at P3): avg {avg / 1e3:.1f} us over {n} launches"
               f" = {966.3676416e9 / (avg * 1e-9) / 1e12:.1f} TFLOP/s at 966.37 GFLOP per launch (B=32, 640x640; profiled passes clock lower than the un-profiled bench)")
 
 

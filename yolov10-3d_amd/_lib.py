@@ -90,6 +90,4 @@ def lib() -> _Lib:
     global _lib
     if _lib is None:
         _lib = _Lib()
-        if os.environ.get("Y3D_NO_STREAM1X1"):  # A/B switch: 1x1 convolutions through the generic implicit-GEMM kernel
-            _lib.set_stream1x1(0)
     return _lib

@@ -273,12 +273,10 @@ bool pw_plan(int M, int K, int N, PwPlan* pl, int G = 1) {
     if (i < 3 && bns[i + 1] >= N) continue;  // a smaller tile still covers N
     if ((size_t)b * nkc * 128 + 3 * 16384 <= cap) { bn = b; break; }
   }
-  static const char* force = getenv("Y3D_PW_STREAMW");  // probe knob: 1 = streamed weights wherever they apply, 0 = never
   const bool can_stream = N > 64 && nkc >= 2;
   // two resident channel tiles stream the pixels twice: one streamed 256-channel tile measured 15-20 % faster at 40x40 (384 -> 256,
   // 256 -> 256), slower on the 20x20 maps (too few pixel tiles to amortise the weight chunks)
   bool wres = bn != 0 && (cdiv(N, bn) == 1 || (cdiv(N, bn) == 2 && nmt < 200));
-  if (force && can_stream) wres = atoi(force) == 0 && bn != 0;
   if (!wres && !can_stream) {
     if (!bn) return false;
     wres = true;

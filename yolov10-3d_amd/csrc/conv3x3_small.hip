@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
       pv = pv && row <= 2 * TH && col <= 32;
     }
     p_off[n] = (row - 1) * p.xsh + (col - 1) * p.xsw + ((cpos ^ sm_swz<CB>(P)) << 3);
-    p_rc[n] = ((pv & ((cpos ^ sm_swz<CB>(P)) * 8 < Cin) ? row : 255) << 8) | col;  // the chunk this lane FETCHES must hold real channels
+    p_rc[n] = (((pv & ((cpos ^ sm_swz<CB>(P)) * 8 < Cin)) ? row : 255) << 8) | col;  // the chunk this lane FETCHES must hold real channels
   }
   auto issue = [&](int t, int buf) {
     int b, y0, x0;

@@ -317,24 +317,13 @@ int launch_tile_epi(const C3P& p, hipStream_t st) {
 
 }  // namespace
 
-// conv3x3_wide.hip: the bf16 production kernel (persistent, 512-pixel tiles); this file's kernel stays as the fp32 (parity mode) path
-int y3d_conv3x3_wide_launch(int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w,
-                            int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream);
-
-// conv3x3_wide3.hip: the round-3 form (SIMD partners half a phase apart); Y3D_WIDE_V2=1 keeps the round-2 kernel for A/B runs
+// conv3x3_wide3.hip: the bf16 production kernel (persistent, 512-pixel tiles, SIMD partners half a phase apart); this file's kernel stays as
+// the fp32 (parity mode) path and serves the bf16 shapes with too few 512-pixel tiles to fill the chip
 int y3d_conv3x3_wide3_launch(int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w,
                              int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream);
-static int wide_v2() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("Y3D_WIDE_V2"); v = (e && atoi(e)) ? 1 : 0; }
-  return v;
-}
 
-static int v2_max_tiles() {
-  static int v2max = -1;
-  if (v2max < 0) { const char* e = getenv("Y3D_V2_MAX_TILES"); v2max = e ? atoi(e) : 129; }
-  return v2max;
-}
+// with fewer 512-pixel tiles than this (half the CUs) the 256-pixel tiles of this file's kernel fill the chip better
+static int v2_max_tiles() { return 129; }
 
 // tile height the resident-halo kernels would use for this geometry, 0 if the generic implicit GEMM must be used
 int y3d_tile_height(int dtype, int B, int H, int W, int Cg, int Cn, int G, int kh, int kw, int stride, int pad) {
@@ -369,7 +358,6 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
     const long wide_tiles = (long)G * cdiv(B, 32 / th) * p.nty * p.ntx * p.ntc;
     if (wide_tiles < v2_max_tiles() && Cg % 64 == 0 && H % th == 0)  // this kernel's K slab is a 128-byte row: 64 bf16 channels
       return th == 16 ? launch_tile_epi<bf16_t, 16>(p, st) : launch_tile_epi<bf16_t, 8>(p, st);
-    if (wide_v2() && Cg % 32 == 0 && Cg >= 64) return y3d_conv3x3_wide_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
     return y3d_conv3x3_wide3_launch(th, x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
   }
   return th == 16 ? launch_tile_epi<float, 16>(p, st) : launch_tile_epi<float, 8>(p, st);

@@ -290,13 +290,11 @@ int y3d_wgrad_tile_splits(int th, int B, int H, int W, int Cg, int Cn, int G) {
   // one round of workgroups: TH = 8 leaves room for one workgroup per CU (112 KB LDS), TH = 4 for two.  More splits only add slab
   // traffic (each workgroup writes its 9 x 128 x 64 fp32 accumulators) and a ragged second round: 512 -> 256 measured +2 % on the
   // head layers, +12 % at 40x40, +35-40 % on 96- / 192-channel body layers
-  static int target8 = 0;
-  if (!target8) { const char* e = getenv("Y3D_WG_TARGET"); target8 = e ? atoi(e) : 256; }
+  const int target8 = 256;
   // rounded DOWN: 27 channel blocks (192 -> 1152, the M head) x 10 splits = 270 workgroups ran as a full round plus a 14-workgroup tail
   // of the same length (733 TFLOP/s against 1 110 for the S head, whose 32 blocks x 8 fill the 256 CUs exactly); 9 splits = 243 fit one
-  static const bool ceil_splits = getenv("Y3D_WG_CEIL") != nullptr;  // A/B knob: the previous rounding
   const long tgt = th == 8 ? target8 : 2 * target8;
-  long want = ceil_splits ? cdiv(tgt, blocks) : tgt / blocks;
+  long want = tgt / blocks;
   if (want > ntiles) want = ntiles;
   long slab_bytes = (long)G * Cn * 9 * Cg * 4;
   long cap = (64L << 20) / slab_bytes;  // keep the fp32 partial slabs of one layer under ~64 MB

@@ -1,24 +1,41 @@
-// bf16 3x3 stride-1 "same" convolution, resident-halo implicit GEMM, persistent workgroups - round-3 form of conv3x3_wide.hip:
-// the same tile, LDS image, DMA streams and epilogue, but the two waves of a SIMD run HALF A PHASE APART ("ping-pong").
+// bf16 3x3 stride-1 "same" convolution, resident-halo implicit GEMM, PERSISTENT workgroups - the kernel that carries the YOLOv10-3D
+// head (83 % of S-3D forward FLOPs are 3x3 convs at 128 channels per group) and, with the taps flipped, its data gradient.
 //
-// What round 2 measured: with both waves of a SIMD on the same schedule - DMA issue, fragment reads, 32 MFMAs, wait,
-// barrier - the matrix pipe idles while both read / issue / wait and both compete for it while both compute: a stage took 1 430-1 630
-// cycles for 1 024 cycles of matrix work, and no re-placement inside that structure got past 0.50 of the MFMA peak.
+// Tile: NB images x (TH x 16) pixels x 128 output channels of one group, NB * TH = 32 (TH = 16: two images, TH = 8: four) - 512 pixels
+// share every weight byte brought on chip, and batching over IMAGES instead of widening the spatial tile keeps the tiling exact for
+// 80x80 / 40x40 maps.  8 waves = 2 channel halves x 4 pixel groups; a wave owns 64 channels x 128 pixels (8 rows of one image): 128
+// accumulator registers.  K runs over (32-channel slab, filter tap): one stage = one tap of one slab = one 16x16x32 MFMA k-step.
+//   * the (TH+2) x 18 halo of the NB images of a slab (64-byte rows, pieces swizzled by the pixel's column) is brought into LDS once and
+//     serves all nine taps; three halo buffers at TH = 16: the halo of slab s+2 streams in while slab s is computed (HBM latency under
+//     load is ~2 us, one slab is ~8 us of MFMA work);
+//   * the 128 x 32 weight tile of a tap (8 KB, L2-resident) streams through a 4-slot ring, three taps in flight;
+//   * both by LDS-DMA (buffer_load ... lds, 16 B per lane: no VGPR staging, no ds_write) with the bank swizzle applied on the per-lane
+//     SOURCE offset (the DMA destination is lane-linear); zero padding = the buffer descriptor's range check;
+//   * the nine stages of a slab are unrolled: LDS offsets are immediates, wait counts compile-time constants; a stage ends with a
+//     COUNTED s_waitcnt vmcnt(N) + raw s_barrier, the younger loads stay in flight across it;
+//   * the two streams have different latencies and vmcnt retires in order, so they are issued by DIFFERENT waves: waves 0..3 (one per
+//     SIMD) stream halos, waves 4..7 weights, each group with its own wait counts.
+// The workgroup is persistent (one per CU): while the last slabs of a tile are computed the first halos and taps of the NEXT tile
+// stream in, and the epilogue's stores drain behind the next tile's MFMAs (the first wait of a tile tolerates them in the vmcnt FIFO).
+// XCD x walks a contiguous run of tiles, its workgroups interleaved, so the tiles in flight share weights and halos in that XCD's L2.
+// Output channels are permuted inside the MFMA row index (row r of channel tile ct is channel (ct>>1)*32 + (r>>2)*8 + (ct&1)*4 + (r&3)),
+// so a lane ends with two runs of 8 consecutive channels and one store instruction writes 64 contiguous bytes per pixel (with 16-byte
+// pieces at a 32-byte stride the L2 wrote 1.8x the tensor: PMC WRITE_SIZE).  The epilogue also emits the per-tile BatchNorm partial sums
+// (sum, sum of squares of the ROUNDED outputs) or applies the eval-mode affine + SiLU.
+// Register budget: the build must stay spill-free - a scratch reload in the loop makes the compiler wait vmcnt(0) and drains the DMA
+// pipeline (seen: -25 %); DMA addresses are recomputed at the issue point from tile scalars (an opaque asm keeps LICM from hoisting them).
+//
+// Round 3 - the two waves of a SIMD HALF A PHASE APART ("ping-pong").  Round 2 measured: with both waves of a SIMD on the same schedule
+// (DMA issue, fragment reads, 32 MFMAs, wait, barrier) the matrix pipe idles while both read / issue / wait and both compete for it
+// while both compute: a stage took 1 430-1 630 cycles for 1 024 cycles of matrix work (738 TFLOP/s for the first resident-halo kernel ->
+// 870 unrolled taps + counted waits -> 1 069 in the training step), and no re-placement inside that structure got past 0.50 of the peak.
 // Here a stage is two phases, each  L: [fragment reads + one DMA instruction + waits] | barrier | M: [16 MFMAs] | barrier,  and waves
-// 4..7 execute ONE barrier more than waves 0..3 before the K loop of a tile (waves 0..3 one more after it): whenever waves 0..3 are
-// in an M segment their SIMD partners are in an L segment and vice versa.  The fragments of a phase are read right before its MFMAs
-// (no double buffer: 16 fewer registers), behind the partner's matrix work.
-// The halo address arithmetic had to shrink for that (an L segment lasts 16 MFMAs = 256 cycles, and the partner's MFMAs leave the
-// VALU half of its issue slots): a halo DMA instruction now covers 16 CONSECUTIVE halo pixels of one image, so image, halo row and
+// 4..7 execute ONE barrier more than waves 0..3 before the K loop of a tile (waves 0..3 one more after it): whenever waves 0..3 are in
+// an M segment their SIMD partners are in an L segment and vice versa.  The fragments of a phase are read right before its MFMAs (no
+// double buffer: 16 fewer registers), behind the partner's matrix work.  The halo address arithmetic had to shrink for that (an L
+// segment lasts 16 MFMAs = 256 cycles): a halo DMA instruction covers 16 CONSECUTIVE halo pixels of one image, so image, halo row and
 // first column are wave-uniform (SALU) and a lane adds at most one row wrap: ~14 VALU instructions per instruction instead of ~35.
-// Weight rows: per-lane offsets computed once.
-//
-// Tile: NB images x (TH x 16) pixels x 128 output channels of one group, NB * TH = 32; 8 waves = 2 channel halves x 4 pixel groups, a
-// wave owns 64 channels x 128 pixels (8 rows of one image).  K runs over (32-channel slab, tap): stage = one 16x16x32 k-step.
-// LDS: NHB halo buffers [img][(TH+2) x 18 pixels][64 B] (pieces swizzled by the pixel's column), a 4-slot ring of 128 x 64 B weight
-// tiles (three taps in flight), all filled by LDS-DMA with counted vmcnt waits; zero padding = the buffer descriptor's range check.
-// Waves 0..3 stream halos, waves 4..7 weights (separate vmcnt FIFOs).  See conv3x3_wide.hip for the measurements behind the LDS
-// image, the epilogue's store order and the output-channel permutation, which are unchanged.
+// (The round-2 kernel, conv3x3_wide.hip, was retired in round 4; tools/probe keeps the probe copy of this one.)
 #include "common.h"
 
 namespace {
@@ -102,7 +119,6 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
     tile = lo + slot;
   }
   if (tile >= tile_end) return;  // uniform per workgroup
-
   struct TileC { int g, b0, y0, x0, c0, ty, tx, live; };
   auto decode = [&](int t, bool live) {
     TileC c;
@@ -292,7 +308,7 @@ __device__ __forceinline__ void wide3_body(const W3P& p) {
     if (HROLE) __builtin_amdgcn_s_barrier();  // the leading group waits here for the trailing group's last M segment: aligned again
 
     // ---- epilogue: this lane holds channels cl(h) .. cl(h)+7, h = 0 / 1, of pixels (wrow0 + pt, lp) of image b0 + wimg.  The two
-    // 64-byte halves of a pixel's 128-byte line are stored back to back (conv3x3_wide.hip) ---------------------------------------------
+    // 64-byte halves of a pixel's 128-byte line are stored back to back ---------------------------------------------------------------
     // lane-derived epilogue values are recomputed HERE from an opaque copy of the lane id: derived before the K loop (where the compiler
     // would hoist them, the tile's coordinates being known there) they are carried through it in registers the loop does not have
     int el = ltid;

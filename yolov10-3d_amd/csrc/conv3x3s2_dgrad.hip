@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_kernel(S2P p) {
     const int P = s8 * 8 + (lane >> 3);
     const int row = P / HW, col = P - row * HW;
     p_off[n] = (row * p.Wo + col) * p.dsw + sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3);
-    p_rc[n] = (((P < (TH + 1) * HW) & (sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3) < p.Cout) ? row : 255) << 8) | col;
+    p_rc[n] = ((((P < (TH + 1) * HW) & (sl * 64 + (((lane & 7) ^ (lane >> 3)) << 3) < p.Cout)) ? row : 255) << 8) | col;
   }
   auto issue = [&](int t, int buf) {
     int b, hy0, wx0;

@@ -723,10 +723,9 @@ int launch_conv_mode(ConvP p, hipStream_t st) {
   // channel tile: 128 wide, unless that leaves most of the chip idle - the stride-32 level (20x20, B = 32: 100 pixel tiles) ran a
   // 4 608-deep reduction on 100 workgroups (512 -> 128 3x3: 97 us, 155 TFLOP/s); narrower tiles put 2-4x as many workgroups to work
   // on the same reduction depth
-  static const char* nosplit = getenv("Y3D_GEMM_WIDE_ONLY");  // A/B knob
   const long t128 = (long)p.ntx * cdiv(p.Cn, 128) * ny * p.G;
   int bc = p.Cn > 64 ? 128 : (p.Cn > 32 ? 64 : 32);
-  if (!nosplit && p.Cn % 32 == 0) {
+  if (p.Cn % 32 == 0) {
     if (bc == 128 && t128 < 192) bc = 64;
     if (bc == 64 && (long)p.ntx * cdiv(p.Cn, 64) * ny * p.G < 192 && p.Cn > 32) bc = 32;
   }
@@ -822,12 +821,10 @@ int y3d_conv2d_wgrad_plan(int dtype, int B, int H, int W, int Cin, int Cout, int
   if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && groups == 1 && y3d_wgrad1x1_stream_ok(dtype, (long)B * H * W, Cin, Cout, Cin, Cout)) {
     // the streaming kernel keeps one 512-thread workgroup per CU busy (148 KB of LDS ring): one round of workgroups, at least four
     // 64-pixel steps each; every further split is one more fp32 slab to write and to fold
-    static int target = 0;
-    if (!target) { const char* e = getenv("Y3D_WG1_TARGET"); target = e ? atoi(e) : 256; }
+    const int target = 256;
     const long tiles = (long)cdiv(Cin, Cin <= 64 ? 64 : 128) * cdiv(Cout, Cout <= 64 ? 64 : 128);
     // rounded down, as y3d_wgrad_tile_splits: 15 tiles (640 -> 320, X widths) x 18 splits = 270 workgroups = a second round for 14 of them
-    static const bool ceil_splits = getenv("Y3D_WG_CEIL") != nullptr;  // A/B knob: the previous rounding
-    long want = ceil_splits ? cdiv(target, tiles) : target / tiles, maxs = cdiv((long)B * H * W, 4 * 64);
+    long want = target / tiles, maxs = cdiv((long)B * H * W, 4 * 64);
     if (want > maxs) want = maxs;
     return (int)(want < 1 ? 1 : want);
   }

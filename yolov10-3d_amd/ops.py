@@ -57,7 +57,7 @@ def nhwc_empty(B, C, H, W, dtype, device):
 # ---- output placement: a producer writes its result straight into a channel slice of its consumer's concat buffer ----------------
 # (C2f / SPPF / Upsample -> Concat: the reference's torch.cat, block.py:236 / :176, conv.py:404, becomes a no-op instead of one copy per
 # input; every kernel on this path takes a pixel stride, so a channel slice of a wider NHWC buffer is an ordinary operand.)
-PLACEMENT = not os.environ.get("Y3D_NO_PLACE")  # A/B switch
+PLACEMENT = True  # tests flip it for A/B comparisons against copying
 _PLACE = None
 
 
@@ -492,9 +492,9 @@ def fp8_weight(ent, Cg):
         lib().fp8_pack_weight_fwd(ent["codes"].data_ptr(), ent["scale"].data_ptr(), rows, Cg, wq.data_ptr(), ws.data_ptr(), stream())
         hit = ent["wq"] = (tok, wq, ws)
     return hit[1], hit[2]
-PROJ_BN_MFMA = not os.environ.get("Y3D_NO_PROJ_BN_MFMA")  # A/B switch: BatchNorm backward of the second head layer recomputing dz on MFMA
-STEM_FUSED = not os.environ.get("Y3D_NO_STEM_FUSED")  # A/B switch: eval stem as im2col + dense conv (the training form) instead of one pass
-PACK_CACHE = not os.environ.get("Y3D_NO_PACK_CACHE")  # A/B switch: per-conv packing launches instead of the registry
+PROJ_BN_MFMA = True  # BatchNorm backward of the second head layer recomputing dz on MFMA (tests flip it: materialised path)
+STEM_FUSED = True  # the stem in one pass (tests flip it: im2col + dense conv)
+PACK_CACHE = True  # weight packs through the registry (one multi-tensor launch per step)
 
 
 # ------------------------------------------------------------------------------------------------------
