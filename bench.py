@@ -298,13 +298,32 @@ def main(argv=None):
     train_ips = world * B * args.steps / dt_s
 
     train_graph_ips = None
-    if not args.no_train_graph and world == 1 and reducer is None:
-        # the same step - forward, loss, backward, clip, SGD - replayed from one captured hipGraph, EMA eagerly behind it; the batches
-        # rotate through the graph's static buffers
+    if not args.no_train_graph and net is model:
+        # the same step - forward, loss, backward, (N > 1: the reducer's bucket all-reduces on their side stream,) clip, SGD - replayed
+        # from one captured hipGraph, EMA eagerly behind it; the batches rotate through the graph's static buffers.  Every rank
+        # captures and replays the same graph, so the collectives inside line up as they do in the eager loop.
+        watchdog = None
+        if dist.is_initialized():
+            # a capture or replay that hangs inside a collective must not cost the run its (already measured) eager number: after 240 s
+            # rank 0 prints the line with the eager rate and every rank leaves
+            import threading
+
+            def bail():
+                if rank == 0:
+                    print(json.dumps({"metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                                      "warmup": args.warmup, "ms_per_step": round(1e3 * world * B / train_ips, 3), "higher_is_better": True, "scaling": "weak",
+                                      "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                                      "config": {"workload": f"{args.model}, {S}x{S}, {args.dtype}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
+                                                 "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
+                                      "train_mode": "eager", "note": "the hipGraph leg of the data-parallel step did not finish within 240 s: eager rate only"}), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(240.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             from yolov10_3d_amd.graph import GraphedTrainStep
             opt.zero_grad(set_to_none=True)
-            gstep = GraphedTrainStep(model, opt, batches[0], max_norm=10.0)
+            gstep = GraphedTrainStep(model, opt, batches[0], max_norm=10.0, reducer=reducer)
             for j in range(2):
                 gstep(batches[j % NBATCH])
                 if ema is not None:
@@ -317,12 +336,18 @@ def main(argv=None):
                     ema.update(model, guard=opt.last_norm)
             sync()
             tg = time.perf_counter() - tg
+            tgm = torch.tensor([tg], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tgm, op=dist.ReduceOp.MAX)
+            tg = float(tgm)
             assert torch.isfinite(gitems).all(), f"non-finite loss items from the graphed step {gitems}"
-            train_graph_ips = B * args.steps / tg
+            train_graph_ips = world * B * args.steps / tg
             log(f"graph-replayed train step: {1e3 * tg / args.steps:.2f} ms/step ({train_graph_ips:.1f} images/s)")
             opt.zero_grad(set_to_none=True)
         except Exception as e:
             log(f"hipGraph capture of the training step failed ({type(e).__name__}: {e})")
+        if watchdog is not None:
+            watchdog.cancel()
 
     # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190: "Speed: ... ms per image").  The forward
     # is ~200 launches of 3-150 us: enqueued eagerly the host is the bound (tools/eval_audit.py), so the timed loop replays ONE captured

@@ -1144,3 +1144,69 @@ def test_grouped_1x1_streaming_kernel_exact(G, Cg, Cn, hw, B):
         assert torch.equal(yy, ref_y), f"y ({which})"
         assert torch.equal(stt, ref_st), f"BatchNorm partial sums ({which})"
         assert torch.equal(dxx, ref_dx), f"dx ({which})"
+
+
+def test_bench_configuration_bf16_step_tracks_the_exact_fp32_step():
+    """BASELINE configs[1] exactly as bench.py runs it - YOLOv10-S + 3D head, 640x640, B = 32, bf16, synth_batch seed 1 - against the SAME
+    step in the exact-fp32 mode of the same kernels on the GPU (the mode the oracle tests hold to the reference within 1e-3): loss items,
+    the assigner's foreground masks, every parameter's gradient norm.  Bounds are ~1.5-2x what was measured on an MI355X (printed).  At
+    random init the alignment metrics are nearly tied, so bf16 rounding re-assigns 20 % of the one-to-many and 35 % of the one-to-one
+    positives; the loss items (averages over all positives) still agree within 1.6 % / 8 %."""
+    import bench
+    torch.manual_seed(0)
+    model = y3d.YOLOv10_3DDetectionModel("yolov10s_3D.yaml").to(DEV).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = bench.synth_batch(32, 640, 640, 1, DEV)
+    res = {}
+    try:
+        for dt in (torch.float32, torch.bfloat16):
+            y3d.set_compute_dtype(dt)
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            loss, items = model(batch)
+            loss.backward()
+            crit = model.criterion
+            fg = [crit.one2many.last_assignment[0].clone(), crit.one2one.last_assignment[0].clone()]
+            gi = [crit.one2many.last_assignment[1].clone(), crit.one2one.last_assignment[1].clone()]
+            norms = {k: float(p.grad.float().norm()) for k, p in model.named_parameters() if p.grad is not None}
+            res[dt] = (items.float().cpu(), fg, gi, norms)
+            assert torch.isfinite(items).all()
+    finally:
+        y3d.set_compute_dtype(torch.bfloat16)
+    i32, fg32, gi32, n32 = res[torch.float32]
+    i16, fg16, gi16, n16 = res[torch.bfloat16]
+    rel = ((i16 - i32).abs() / i32.abs().clamp(min=1e-6)).tolist()
+    agree = []
+    for a, b, ga, gb in zip(fg32, fg16, gi32, gi16):
+        both = (a & b)
+        agree.append((float(both.sum()) / float(a.sum()), float((both & (ga == gb)).sum()) / float(a.sum()), int(a.sum()), int(b.sum())))
+    # gradients that are zero in exact arithmetic (a BatchNorm bias in front of another BatchNorm) are pure rounding noise in both modes:
+    # norms are compared on the scale of the largest one
+    floor = 1e-3 * max(n32.values())
+    ratios = sorted((n16[k] / n32[k], k) for k in n32 if n32[k] > floor)
+    dev = sorted((abs(n16[k] - n32[k]) / (n32[k] + floor), k) for k in n32)
+    print(f"bf16 vs exact fp32 at the bench configuration: loss items rel. diff {[round(v, 4) for v in rel]}")
+    print(f"  foreground agreement (fraction of fp32 positives kept, kept with the same box, #fp32, #bf16): one-to-many {agree[0]}, one-to-one {agree[1]}")
+    print(f"  gradient-norm ratio bf16 / fp32 over {len(ratios)} parameters: median {ratios[len(ratios) // 2][0]:.4f}, worst {dev[-1]}, 99th percentile {dev[int(0.99 * len(dev))]}")
+    assert max(rel[:6]) < 0.035, f"one-to-many loss items: {rel[:6]}"
+    assert max(rel[6:]) < 0.16, f"one-to-one loss items: {rel[6:]}"
+    assert agree[0][1] > 0.65 and agree[1][1] > 0.5, agree  # random init: near-tied metrics, the discrete choice is fragile (measured 0.80 / 0.65)
+    # measured: median 1.5 %, 99th percentile 34 %, worst 46 % - the tail is the P5-level branches of the one-to-one set, whose gradient is the
+    # sum over a few dozen positives of which bf16 rounding re-assigns a third at random init (agreement above); the body follows the median
+    p50, p90 = dev[len(dev) // 2][0], dev[int(0.9 * len(dev))][0]
+    print(f"  |norm16 - norm32| / norm32: median {p50:.4f}, 90th percentile {p90:.4f}")
+    assert p50 < 0.04 and p90 < 0.25 and dev[int(0.99 * len(dev))][0] < 0.5 and dev[-1][0] < 0.7, (p50, p90, dev[-3:])
+
+
+def test_captured_data_parallel_step_matches_the_eager_reducer_step():
+    """the N > 1 step (forward, loss, backward with the reducer's hook-driven bucket gathers + RCCL all-reduces,
+    clip, SGD) recorded into ONE hipGraph - rehearsed on one GPU as a process group of size 1 over RCCL (Y3D_FORCE_DDP=1: the collectives
+    are issued and captured) - leaves the model where the eager reducer step leaves it, bit for bit (tools/probe/ddp_graph_probe.py, in
+    a child process: it owns a process group and a segfault of the runtime must not take the suite down)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, Y3D_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probe", "ddp_graph_probe.py")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "captured reducer step == eager reducer step: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -158,6 +158,9 @@ class FlatGradReducer:
         self.last_times = None
         self._sync = True
         self._any, self._nfinish = None, 0  # which parameters have a gradient on some rank (finish())
+        # one-rank rehearsals (Y3D_FORCE_DDP=1: a process group of size 1 over RCCL) issue the collectives too, so that the whole N > 1
+        # code path - including its capture into a hipGraph - runs on a one-GPU box
+        self.always_collective = bool(os.environ.get("Y3D_FORCE_DDP"))
 
     def no_sync(self):
         """context manager for the non-final micro-steps of gradient accumulation (torch DDP's `no_sync`)"""
@@ -254,9 +257,22 @@ class FlatGradReducer:
             grads.append(g)
         lo = self.offs[a]
         hi = self.offs[e - 1] + self.sizes[e - 1]
-        multi = dist.is_initialized() and dist.get_world_size() > 1
-        if self.comm is not None:
-            ev = torch.cuda.Event(enable_timing=self.timing)
+        multi = dist.is_initialized() and (dist.get_world_size() > 1 or self.always_collective)
+        capturing = self.comm is not None and torch.cuda.is_current_stream_capturing()
+        timing = self.timing and not capturing  # (timing events cannot be recorded into a hipGraph capture)
+        if capturing:
+            # inside a hipGraph capture (graph.GraphedTrainStep): gather + collective on the capturing stream itself - no side stream to
+            # fork and join inside the capture; the graph's node order is the eager order of one stream
+            for i in stale:
+                self.views[i].zero_()
+                self._dirty[i] = False
+            if idx:
+                self._gather(idx, grads)
+            if multi:
+                dist.all_reduce(self.flat[lo:hi])
+            self._keep.append(grads)
+        elif self.comm is not None:
+            ev = torch.cuda.Event(enable_timing=timing)
             ev.record()  # compute stream: everything that produced this bucket's gradients has been enqueued
             self.comm.wait_event(ev)
             with torch.cuda.stream(self.comm):
@@ -268,12 +284,12 @@ class FlatGradReducer:
                 if idx:
                     self._gather(idx, grads)
                 t0 = t1 = None
-                if self.timing:
+                if timing:
                     t0 = torch.cuda.Event(enable_timing=True)
                     t0.record()
                 if multi:
                     dist.all_reduce(self.flat[lo:hi], async_op=True).wait()
-                if self.timing:
+                if timing:
                     t1 = torch.cuda.Event(enable_timing=True)
                     t1.record()
                     self._events.append((ev, t0, t1, hi - lo))
@@ -297,11 +313,13 @@ class FlatGradReducer:
             self._next += 1
         for w in self._works:
             w.wait()
-        if self.comm is not None:
+        if self.comm is not None and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream().wait_stream(self.comm)
         local = [p.grad is not None for p in self.params]
         take = local
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized() and dist.get_world_size() > 1 and (self._any is None or not torch.cuda.is_current_stream_capturing()):
+            # (while a hipGraph of the step is being captured the exchange below - a host read - cannot run: the mask of the warm-up
+            # steps before the capture is used, graph.GraphedTrainStep)
             # a parameter whose gradient exists on ANOTHER rank only must still receive the reduced sum here (torch DDP hands every rank
             # the reduced gradient), or this rank's optimizer would skip it and the replicas drift apart (round-3 advisor finding).  Which
             # parameters have a gradient on some rank is a property of the graph: it is exchanged at the first finish() and re-checked
@@ -312,6 +330,8 @@ class FlatGradReducer:
                 self._any = [bool(v) for v in t.cpu().tolist()]
             self._nfinish += 1
             take = [a or b for a, b in zip(self._any, local)]
+        if dist.is_initialized() and dist.get_world_size() > 1 and self._any is not None and take is local:
+            take = [a or b for a, b in zip(self._any, local)]  # capturing: the cached mask
         for i, p in enumerate(self.params):
             if take[i]:
                 p.grad = self.views[i]

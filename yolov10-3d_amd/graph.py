@@ -74,6 +74,12 @@ class GraphedTrainStep:
     keeps its count on the device (loss.pad_targets); the optimizer's skip of non-finite steps and AdamW's step count live on the
     device (csrc/optim.hip); pointer tables travel through pinned buffers (optim.PtrUploader).
 
+    N > 1: pass the `ddp.FlatGradReducer` - its bucket gathers and RCCL all-reduces are recorded into the graph (on the capturing stream:
+    no side stream is forked inside a capture), every rank captures and replays the same sequence of collectives.
+    Before constructing one, DROP every reference to an earlier step's autograd graph (`del loss`): a live graph keeps its
+    AccumulateGrad nodes, which belong to the stream they were made on - the NULL stream for an eager step - and a capture that has to
+    touch that stream dies in hipStreamEndCapture (torch warns "AccumulateGrad node's stream does not match"; seen as a segfault).
+
     Constructing one does NOT train: the warm-up steps it needs run on the first batch and are undone (parameters, BatchNorm buffers,
     optimizer state and step counts are restored in place before the capture).
 
@@ -84,12 +90,12 @@ class GraphedTrainStep:
     After every replay the host-side bookkeeping the captured Python code would have done is redone: BatchNorm `num_batches_tracked`
     counters and the parameter epochs that the eval caches / weight packs key on."""
 
-    def __init__(self, model, opt, batch, max_norm: float | None = 10.0, label_capacity: int | None = None, warmup: int = 2):
+    def __init__(self, model, opt, batch, max_norm: float | None = 10.0, label_capacity: int | None = None, warmup: int = 2, reducer=None):
         from . import loss as _loss
         from .ddp import PER_BOX_KEYS
         from .modules import Conv
         from .optim import PtrUploader
-        self.model, self.opt, self.max_norm = model, opt, max_norm
+        self.model, self.opt, self.max_norm, self.reducer = model, opt, max_norm, reducer
         self.box_keys = tuple(k for k in (("batch_idx",) + PER_BOX_KEYS) if k in batch)
         B = batch["img"].shape[0]
         self.cap = int(label_capacity or 64 * B)
@@ -124,13 +130,17 @@ class GraphedTrainStep:
         had_state = opt._state is not None
         opt_snap = (opt._state["flat"].clone(), opt._state["norm_clip"].clone()) if had_state else None
         steps0 = opt._steps
+        if reducer is not None:
+            # the reducer's gather tables (source pointers through rotating pinned buffers): the warm-up below builds fresh ones, the capture
+            # bakes their addresses in, and they are then set aside for the graph alone (eager steps build their own) - as the optimizer's
+            reducer._tabs = {}
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(max(2, warmup)):
                 self._body()
-                opt.zero_grad(set_to_none=True)
+                opt.zero_grad(set_to_none=True)  # (under a reducer: p.grad was the reduced slot; the next backward starts from None)
             with torch.no_grad():
                 for t, v in zip(tensors, snap):
                     t.copy_(v)
@@ -155,6 +165,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.items = self._body()
+        if reducer is not None:
+            self._red_tabs, reducer._tabs = reducer._tabs, {}  # kept alive for the replays; eager steps build new ones
         self._gup = st["gup"]  # kept alive: the graph's memcpy node reads its pinned buffer at every replay
         st["gup"], st["gkey"] = None, None
         # every device table the captured optimizer launches read (sizes, chunk maps, lr / wd, parameter and state pointers): the optimizer
@@ -173,6 +185,11 @@ class GraphedTrainStep:
     def _body(self):
         loss, items = self.model(self.static)
         loss.backward()
+        if self.reducer is not None:
+            # N > 1 (ddp.FlatGradReducer): the bucket gathers and RCCL all-reduces that the gradient hooks launched on the reducer's side
+            # stream during the backward above, and the join below, are part of the captured graph - a forked branch beside the body
+            # backward, exactly the eager overlap - so a replay runs the whole data-parallel step with one host call
+            self.reducer.finish()
         self.opt.step(max_norm=self.max_norm)
         return loss.detach(), items
 
