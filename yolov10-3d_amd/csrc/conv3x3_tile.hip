@@ -322,6 +322,13 @@ int launch_tile_epi(const C3P& p, hipStream_t st) {
 int y3d_conv3x3_wide3_launch(int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w,
                              int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream);
 
+// conv3x3_flat.hip: the same pipeline over the flattened padded pixel space (tiles of 512 consecutive positions): the better tiling where
+// 16-pixel tile rows / 8- or 16-row tiles do not divide the map (40x40, 20x20).  Tile height code -1.
+int y3d_conv3x3_flat_ok(int B, int H, int W, int Cg, int Cn, int G);
+int y3d_conv3x3_flat_tiles(int B, int H, int W);
+int y3d_conv3x3_flat_launch(const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G, const void* w, int Ktot, void* y,
+                            long ysw, float* part, int flip, const float* scale, const float* shift, int act, void* stream);
+
 // with fewer 512-pixel tiles than this (half the CUs) the 256-pixel tiles of this file's kernel fill the chip better
 static int v2_max_tiles() { return 129; }
 
@@ -334,6 +341,14 @@ int y3d_tile_height(int dtype, int B, int H, int W, int Cg, int Cn, int G, int k
   if (dtype == Y3D_BF16 ? (Cg % 8 != 0 || Cg < 40 || (Cg < 64 && Cg % 32 != 0 && Cn <= 64)) : (Cg % cse != 0 || Cg < 64)) return 0;
   if (Cn % 16 != 0) return 0;
   if (W < 8) return 0;
+  if (dtype == Y3D_BF16 && y3d_conv3x3_flat_ok(B, H, W, Cg, Cn, G)) {
+    // the flat tiling when it needs at least 4 % fewer tiles than the rectangular one (and enough of them to fill the chip).  Same-box A/B
+    // (tools/conv_bench.py, B = 32): 512 -> 2048 @20x20 forward 0.341 -> 0.252 ms (710 -> 959 TFLOP/s), 256 -> 2048 @40x40 0.484 -> 0.459,
+    // 16 x (128 -> 128) @40x40 0.292 -> 0.282; the 20x20 data gradients (124 tiles: one round of half the CUs either way) do not move
+    const int thr = H % 16 == 0 ? 16 : 8;
+    const long rect = (long)cdiv(B, 32 / thr) * cdiv(H, thr) * cdiv(W, 16), flat = y3d_conv3x3_flat_tiles(B, H, W);
+    if (flat * 104 < rect * 100 && flat * G * cdiv(Cn, 128) >= v2_max_tiles()) return -1;
+  }
   if (H % 16 == 0) return 16;
   if (H % 8 == 0) return 8;
   // ragged height (20x20: the stride-32 level of a 640x640 image): the persistent bf16 kernel runs ceil(H / 8) row tiles and masks the
@@ -352,6 +367,7 @@ int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh
   p.B = B; p.H = H; p.W = W; p.Cg = Cg; p.Cn = Cn; p.G = G; p.Ktot = Ktot;
   p.ntx = cdiv(W, 16); p.nty = cdiv(H, th); p.ntc = cdiv(Cn, 128); p.flip = flip;
   hipStream_t st = (hipStream_t)stream;
+  if (th < 0) return y3d_conv3x3_flat_launch(x, xsb, xsh, xsw, B, H, W, Cg, Cn, G, w, Ktot, y, ysw, part, flip, scale, shift, act, stream);
   if (dtype == Y3D_BF16) {
     // the persistent kernel runs one 512-pixel tile per CU at a time: with fewer tiles than half the CUs (128 -> 128 @40x40, B = 32:
     // 120) the 256-pixel tiles of this file's kernel fill the chip better (628 / 671 against 448 / 482 TFLOP/s forward / dgrad)

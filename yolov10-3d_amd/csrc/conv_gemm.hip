@@ -754,6 +754,7 @@ int launch_conv(ConvP p, hipStream_t st) {
 
 // conv3x3_tile.hip
 int y3d_tile_height(int dtype, int B, int H, int W, int Cg, int Cn, int G, int kh, int kw, int stride, int pad);
+int y3d_conv3x3_flat_tiles(int B, int H, int W);
 int y3d_conv3x3_tile_launch(int dtype, int th, const void* x, long xsb, long xsh, long xsw, int B, int H, int W, int Cg, int Cn, int G,
                             const void* w, int Ktot, void* y, long ysw, float* part, int flip, const float* scale, const float* shift, int act,
                             void* stream);
@@ -840,6 +841,7 @@ int y3d_conv2d_stat_rows(int dtype, int B, int H, int W, int Cin, int Cout, int 
   if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && groups == 1 && y3d_conv3x3_small_s2_ok(dtype, B, H, W, Cin, Cout))
     return y3d_conv3x3_small_s2_rows(B, H, W, Cin, Cout);
   int th = (g_tile_kernels && groups > 0) ? y3d_tile_height(dtype, B, H, W, Cin / groups, Cout / groups, groups, kh, kw, stride, pad) : 0;
+  if (th < 0) return y3d_conv3x3_flat_tiles(B, H, W);  // conv3x3_flat.hip: one row per 512-position tile of the flat padded space
   if (th) return B * cdiv(H, th) * cdiv(W, 16);
   int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   return cdiv((long)B * Ho * Wo, 128);
