@@ -398,7 +398,11 @@ int flat_cu_count() {
 template <int NHB, int EPI>
 int launch_flat(const WFP& p, hipStream_t st) {
   size_t sm = (size_t)NHB * p.HPIX * 64 + 4 * 8192 + 4 * 128 * 2 * 4;
-  (void)hipFuncSetAttribute((const void*)conv3x3_flat_kernel<NHB, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_flat_kernel<NHB, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   long ntiles = (long)p.G * p.ntf * p.ntc;
   long nwg = (long)flat_cu_count() / 8 * 8;
   if (nwg < 8) nwg = 8;
