@@ -95,6 +95,12 @@ BENCH_SHAPES = [
     (72, 160, 1, 24, 24, 2),        # 72 = 2 slabs + 8 channels, two output-channel tiles
     (160, 160, 2, 16, 32, 2),       # two groups of 80 -> 80
     (48, 96, 1, 16, 16, 4),         # 1.5 slabs, Cout > 64 (the narrow kernel does not take it)
+    # round 4: conv3x3_flat.hip (tiles of 512 consecutive positions of the padded flat space) - maps whose rows / columns the rectangular
+    # tiles do not divide, with enough channel tiles for y3d_tile_height to pick it (the P4 / P5 rows above go through it too)
+    (64, 2048, 1, 23, 37, 7),       # odd height and width, odd batch: tiles span rows and images, the last tile is ragged
+    (96, 1536, 3, 20, 20, 9),       # three groups of 32 -> 512: one K slab + 0 (Cg = 32 is below the kernel's 40: stays on the generic path)
+    (80, 1024, 1, 20, 20, 11),      # 2.5 K slabs on the flat kernel
+    (256, 640, 2, 12, 44, 5),       # W + 2 = 46: row wraps inside a 16-position DMA piece; Cn = 320 = 2.5 channel tiles per group
 ]
 
 
