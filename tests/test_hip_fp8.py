@@ -230,3 +230,55 @@ def test_fp8_conv_head_training_step_vs_oracle():
     for a, b, f, what in zip(dist[True], dist[False], fmt, ("head maps", "input gradients", "weight gradients")):
         assert a <= 1.5 * f + b, f"{what}: fp8 path {a:.3e} from its oracle, format noise {f:.3e}, bf16 path {b:.3e} from its own"
     assert 0.5 * fmt[0] <= hip_fmt <= 2 * fmt[0] and 1e-3 < fmt[0] < 0.15
+
+
+def test_fp8_conv_full_model_step_and_eval_track_the_bf16_emulation():
+    """YOLOv10-S + 3D head at 320x320, B = 4, bf16, fp8 weights: the step with the fp8 MFMA convolutions (both head layers, the 128-channel
+    body blocks: 20+ launches) against the SAME step with every product on the bf16 matrix cores (`--fp8-emulate`: fp8-valued weights, bf16
+    activations) - what the activation format costs the loss and the gradients, measured and bounded (the format moves the head maps by
+    ~1e-2, test above; loss items within 5 % / 12 % for the one-to-many / one-to-one set on this batch) - and the eval forward: class maps
+    within 5e-2 of the emulation's through the affine epilogue of the fp8 kernel (at random init the class logits sit at their -11.4 bias,
+    where bf16 keeps 0.06: the bound is an upper bound only - that the eval forward launched the fp8 kernel is what is asserted)."""
+    import bench
+    from test_hip_modules import l2_rel
+    torch.manual_seed(0)
+    y3d.set_compute_dtype(torch.bfloat16)
+    y3d.set_weight_quant("fp8")
+    try:
+        model = y3d.YOLOv10_3DDetectionModel("yolov10s_3D.yaml").to(DEV).train()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        batch = bench.synth_batch(4, 320, 320, 3, DEV)
+        res = {}
+        for mode in (False, True):
+            y3d.set_fp8_conv(mode)
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            seen = []
+            ops.TIMER = ops.KernelTimer(lambda key: seen.append(key[0]) or False)
+            loss, items = model.train()(batch)
+            ops.TIMER = None
+            loss.backward()
+            norms = {k: float(p.grad.float().norm()) for k, p in model.named_parameters() if p.grad is not None}
+            model.load_state_dict(state)
+            seen_e = []
+            ops.TIMER = ops.KernelTimer(lambda key: seen_e.append(key[0]) or False)
+            with torch.no_grad():
+                ev = model.eval()(batch["img"])["one2one"][1]
+            ops.TIMER = None
+            torch.cuda.synchronize()
+            res[mode] = (items.float().cpu(), norms, [m[:, :3].float().cpu() for m in ev], seen.count("conv_fwd_fp8"), seen_e.count("conv_eval_fp8"))
+            assert torch.isfinite(items).all()
+    finally:
+        y3d.set_fp8_conv(False)
+        y3d.set_weight_quant(None)
+    assert res[False][3] == 0 and res[True][3] >= 10, f"fp8 launches: {res[True][3]}"
+    assert res[False][4] == 0 and res[True][4] >= 6, f"fp8 eval launches (affine epilogue): {res[True][4]}"
+    rel = ((res[True][0] - res[False][0]).abs() / res[False][0].abs().clamp(min=1e-6)).tolist()
+    floor = 1e-3 * max(res[False][1].values())
+    dev = sorted(abs(res[True][1][k] - v) / (v + floor) for k, v in res[False][1].items())
+    cls = [l2_rel(a, b) for a, b in zip(res[True][2], res[False][2])]
+    print(f"fp8 MFMA convolutions vs bf16 emulation (S-3D 320^2 B=4): loss items rel. diff {[round(v, 4) for v in rel]}; gradient norms: median "
+          f"{dev[len(dev) // 2]:.4f}, 90th percentile {dev[int(0.9 * len(dev))]:.4f}; eval class maps relative L2 {[round(v, 4) for v in cls]}")
+    assert max(rel[:6]) < 0.05 and max(rel[6:]) < 0.15, rel
+    assert dev[len(dev) // 2] < 0.05 and dev[int(0.9 * len(dev))] < 0.3
+    assert max(cls) < 5e-2

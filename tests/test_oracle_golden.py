@@ -411,3 +411,34 @@ def test_kitti_image_aug_restatement_matches_reference():
     # un-cropped samples: centre = image centre, crop = image size
     t, tinv = RS.get_affine_transform(np.array([160.0, 48.0]), np.array([320.0, 96.0]), (W, H), inv=True)
     assert np.allclose(tinv, z["s0/trans_inv"], atol=1e-9) and np.allclose(t @ np.vstack((tinv, [0, 0, 1])), np.eye(3)[:2], atol=1e-9)
+
+
+def test_fp8_conv_mode_restatement_invariants():
+    """the oracle's restatement of the fp8 MFMA convolution mode (no reference counterpart: BASELINE configs[4] is this build's own format) -
+    its defining properties, on the CPU: (1) an MX block scale is the smallest power of two that brings the block's amax to <= 448, so no
+    code saturates and the dequantised value is within half an e4m3 step (2^-4 relative) of the input, blocks of zeros stay zeros;
+    (2) values that are e4m3-representable at their block's scale come back exactly; (3) the convolution's gradients are those of the
+    UNquantised convolution (straight-through): dx sees w, dW sees x, not their quantised forms."""
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 5, 7) * torch.exp2(torch.randint(-6, 6, (2, 2, 1, 5, 7)).float()).repeat_interleave(32, 2).reshape(2, 64, 5, 7)
+    x[0, :32, 0, 0] = 0
+    q, s, xe = RS.mx_quantize_act(x)
+    blk = x.reshape(2, 2, 32, 5, 7)
+    amax = blk.abs().amax(2)
+    scale = torch.exp2(s.float() - 127)
+    assert bool((amax <= 448 * scale).all()) and bool(((amax > 224 * scale) | (amax == 0)).all()), "not the smallest power of two"
+    assert int(s[0, 0, 0, 0]) == 127 and bool((xe[0, :32, 0, 0] == 0).all())
+    err = (xe - x).abs().reshape(2, 2, 32, 5, 7)
+    assert bool((err <= 2.0 ** -4 * blk.abs() + 2.0 ** -10 * scale.unsqueeze(2)).all())  # half a step: 3 mantissa bits; subnormals: 2^-9 * scale steps
+    exact = torch.randint(-7, 8, (1, 32, 3, 3)).float() * 0.25
+    assert torch.equal(RS.mx_quantize_act(exact)[2], exact)
+    # straight-through gradients
+    w = (torch.randn(16, 128, 3, 3) * 0.1).requires_grad_(True)
+    xin = torch.randn(1, 128, 8, 8).requires_grad_(True)
+    y = RS._Fp8ConvSTE.apply(xin, w, 1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert torch.allclose(xin.grad, torch.nn.grad.conv2d_input(xin.shape, w.detach(), dy, 1, 1, 1, 1), atol=1e-5)
+    assert torch.allclose(w.grad, torch.nn.grad.conv2d_weight(xin.detach(), w.shape, dy, 1, 1, 1, 1), atol=1e-4)
+    assert not torch.allclose(y, torch.nn.functional.conv2d(xin, w, None, 1, 1), atol=1e-4), "the forward must see the quantised input"
+    assert RS.fp8_conv_served(torch.zeros(1, 128, 8, 8), w, 1, 1, 1) and not RS.fp8_conv_served(torch.zeros(1, 128, 8, 8), w, 2, 1, 1)
