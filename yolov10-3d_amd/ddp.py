@@ -317,7 +317,7 @@ class FlatGradReducer:
             torch.cuda.current_stream().wait_stream(self.comm)
         local = [p.grad is not None for p in self.params]
         take = local
-        if dist.is_initialized() and dist.get_world_size() > 1 and (self._any is None or not torch.cuda.is_current_stream_capturing()):
+        if dist.is_initialized() and dist.get_world_size() > 1 and (self._any is None or self.comm is None or not torch.cuda.is_current_stream_capturing()):
             # (while a hipGraph of the step is being captured the exchange below - a host read - cannot run: the mask of the warm-up
             # steps before the capture is used, graph.GraphedTrainStep)
             # a parameter whose gradient exists on ANOTHER rank only must still receive the reduced sum here (torch DDP hands every rank

@@ -614,63 +614,77 @@ class v10Detect3d(nn.Module):
         if self.use_predecessors:
             raise RuntimeError("use_predecessors has no eval path: the reference's patch forward (head.py:694-716) feeds the branches bare "
                                "feature patches and fails on the channel count")
+        if ops.EVAL_LEVEL_STREAMS and self.nl > 1 and x[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # the levels are independent chains of ~9 small launches each (1 600 patches, 40x40 / 20x20 maps: none fills 256 CUs for
+            # long): inside a capture each level is recorded on its own stream, so the hipGraph holds nl parallel branches between the
+            # neck and the decode.  Eagerly the host is the bound and one stream is kept.
+            cur = torch.cuda.current_stream()
+            pool = ops.level_streams(self.nl)
+            ys = [None] * self.nl
+            for i in range(self.nl):
+                pool[i].wait_stream(cur)
+                with torch.cuda.stream(pool[i]):
+                    ys[i] = self._inference_level(x, heads, i)
+            for i in range(self.nl):
+                cur.wait_stream(pool[i])
+            return ys
+        return [self._inference_level(x, heads, i) for i in range(self.nl)]
+
+    def _inference_level(self, x, heads, i):
         ps = self.patch_size
         L = ops.lib()
-        ys = []
-        for i in range(self.nl):
-            xi = ops.to_nhwc(x[i], ops.compute_dtype())
-            B, C, H, W = xi.shape
-            if H * W < self.max_det:
-                raise ValueError(f"level {i} has {H * W} cells < max_det={self.max_det} (reference head.py:690 needs H*W >= max_det)")
-            dt, st = ops.code(xi.dtype), ops.stream()
-            cls = _proj([heads[0][i][2]], [heads[0][i][1](heads[0][i][0](xi))])
-            idx = self.select_candidates(cls)  # (B, K) int32
-            K = idx.shape[1]
-            patches = ops.nhwc_empty(B * K, C, ps, ps, xi.dtype, xi.device)
-            sb, sh, sw = ops.s3(xi)
-            L.patch_gather(dt, xi.data_ptr(), sb, sh, sw, idx.data_ptr(), patches.data_ptr(), B, H, W, C, K, ps, st)
-            # a model folded by the reference's BaseModel.fuse() (no .bn on the branch Convs) runs branch by branch on forward_fuse
-            folded = not hasattr(heads[1][i][0], "bn") if isinstance(heads[1][i][0], Conv) else False
-            _, mids, s1, s2, _, _ = self._stacks(i) if not (self.generic or folded) else (None,) * 6
-            if heads is self.o2o_heads and s2 is not None:
-                # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
-                # (channel rows mid..8*mid of the training-time stacks), both unpadded: patch semantics of head.py:706-708
-                mid, c0 = mids[0], heads[1][i][0]
-                lo, hi = mid, 8 * mid
-                w1, g1, b1, rm1, rv1 = s1.tensors()
-                z1 = ops.conv_bn_act_eval(patches, w1[lo:hi], g1[lo:hi], b1[lo:hi], rm1[lo:hi], rv1[lo:hi], self.kernel_size_1, 1, 0, 1,
-                                          c0.has_act, c0.eps, s1.__dict__.setdefault("_eval_cache", {}), ver=s1.ver)
-                w2, g2, b2, rm2, rv2 = s2.tensors()
-                z2 = ops.conv_bn_act_eval(z1, w2[lo:hi], g2[lo:hi], b2[lo:hi], rm2[lo:hi], rv2[lo:hi], self.kernel_size_2, 1, 0, 7,
-                                          c0.has_act, c0.eps, s2.__dict__.setdefault("_eval_cache", {}), ver=s2.ver)
-                reg = ops.proj_slices_eval(z2, [j * mid for j in range(7)], mid, [heads[j][i][2].weight for j in range(1, 8)],
-                                           [heads[j][i][2].bias for j in range(1, 8)])[:, :, 0, 0]
-            else:
-                feats = []
-                for j in range(1, 8):
-                    br = heads[j][i]
-                    # patch semantics, head.py:706-708: the branch's TOP-LEVEL Conv layers run unpadded (5x5 patch -> 1x1); the nested
-                    # Sequentials of `dsconv` keep their padding there, and so here (the 5x5 result is then read at cell (0, 0) like the
-                    # reference reads it).  Unlike the reference we do not leave the modules mutated.
-                    convs = [l for l in list(br)[:-1] if isinstance(l, Conv)]
-                    pads = [l.conv.padding for l in convs]
-                    for l in convs:
-                        l.conv.padding = (0, 0)
-                    try:
-                        f = patches
-                        for l in list(br)[:-1]:
-                            f = l(f)
-                        feats.append(f)
-                    finally:
-                        for l, p0 in zip(convs, pads):
-                            l.conv.padding = p0
-                reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
-            reg = reg.contiguous()
-            full = ops.nhwc_empty(B, self.no, H, W, cls.dtype, xi.device)
-            L.head3d_scatter(dt, cls.data_ptr(), cls.stride(3), reg.data_ptr(), reg.stride(0), idx.data_ptr(), full.data_ptr(), B, H * W, self.nc,
-                             self.no, K, st)
-            ys.append(full)
-        return ys
+        xi = ops.to_nhwc(x[i], ops.compute_dtype())
+        B, C, H, W = xi.shape
+        if H * W < self.max_det:
+            raise ValueError(f"level {i} has {H * W} cells < max_det={self.max_det} (reference head.py:690 needs H*W >= max_det)")
+        dt, st = ops.code(xi.dtype), ops.stream()
+        cls = _proj([heads[0][i][2]], [heads[0][i][1](heads[0][i][0](xi))])
+        idx = self.select_candidates(cls)  # (B, K) int32
+        K = idx.shape[1]
+        patches = ops.nhwc_empty(B * K, C, ps, ps, xi.dtype, xi.device)
+        sb, sh, sw = ops.s3(xi)
+        L.patch_gather(dt, xi.data_ptr(), sb, sh, sw, idx.data_ptr(), patches.data_ptr(), B, H, W, C, K, ps, st)
+        # a model folded by the reference's BaseModel.fuse() (no .bn on the branch Convs) runs branch by branch on forward_fuse
+        folded = not hasattr(heads[1][i][0], "bn") if isinstance(heads[1][i][0], Conv) else False
+        _, mids, s1, s2, _, _ = self._stacks(i) if not (self.generic or folded) else (None,) * 6
+        if heads is self.o2o_heads and s2 is not None:
+            # the 7 regression branches of the one-to-one set as one stacked conv + one grouped conv on the patches
+            # (channel rows mid..8*mid of the training-time stacks), both unpadded: patch semantics of head.py:706-708
+            mid, c0 = mids[0], heads[1][i][0]
+            lo, hi = mid, 8 * mid
+            w1, g1, b1, rm1, rv1 = s1.tensors()
+            z1 = ops.conv_bn_act_eval(patches, w1[lo:hi], g1[lo:hi], b1[lo:hi], rm1[lo:hi], rv1[lo:hi], self.kernel_size_1, 1, 0, 1,
+                                      c0.has_act, c0.eps, s1.__dict__.setdefault("_eval_cache", {}), ver=s1.ver)
+            w2, g2, b2, rm2, rv2 = s2.tensors()
+            z2 = ops.conv_bn_act_eval(z1, w2[lo:hi], g2[lo:hi], b2[lo:hi], rm2[lo:hi], rv2[lo:hi], self.kernel_size_2, 1, 0, 7,
+                                      c0.has_act, c0.eps, s2.__dict__.setdefault("_eval_cache", {}), ver=s2.ver)
+            reg = ops.proj_slices_eval(z2, [j * mid for j in range(7)], mid, [heads[j][i][2].weight for j in range(1, 8)],
+                                       [heads[j][i][2].bias for j in range(1, 8)])[:, :, 0, 0]
+        else:
+            feats = []
+            for j in range(1, 8):
+                br = heads[j][i]
+                # patch semantics, head.py:706-708: the branch's TOP-LEVEL Conv layers run unpadded (5x5 patch -> 1x1); the nested
+                # Sequentials of `dsconv` keep their padding there, and so here (the 5x5 result is then read at cell (0, 0) like the
+                # reference reads it).  Unlike the reference we do not leave the modules mutated.
+                convs = [l for l in list(br)[:-1] if isinstance(l, Conv)]
+                pads = [l.conv.padding for l in convs]
+                for l in convs:
+                    l.conv.padding = (0, 0)
+                try:
+                    f = patches
+                    for l in list(br)[:-1]:
+                        f = l(f)
+                    feats.append(f)
+                finally:
+                    for l, p0 in zip(convs, pads):
+                        l.conv.padding = p0
+            reg = _proj([heads[j][i][2] for j in range(1, 8)], feats)[:, :, 0, 0]  # (BK, 35)
+        reg = reg.contiguous()
+        full = ops.nhwc_empty(B, self.no, H, W, cls.dtype, xi.device)
+        L.head3d_scatter(dt, cls.data_ptr(), cls.stride(3), reg.data_ptr(), reg.stride(0), idx.data_ptr(), full.data_ptr(), B, H * W, self.nc,
+                         self.no, K, st)
+        return full
 
     def decode(self, ys):
         """head.py:755-797: (B, no, A) fp32 with xyxy px boxes and centre-3d px (HIP kernel over the per-level NHWC maps)."""

@@ -58,6 +58,14 @@ def nhwc_empty(B, C, H, W, dtype, device):
 # (C2f / SPPF / Upsample -> Concat: the reference's torch.cat, block.py:236 / :176, conv.py:404, becomes a no-op instead of one copy per
 # input; every kernel on this path takes a pixel stride, so a channel slice of a wider NHWC buffer is an ordinary operand.)
 PLACEMENT = True  # tests flip it for A/B comparisons against copying
+EVAL_LEVEL_STREAMS = True  # captured eval forward: one hipGraph branch per detection level (modules.v10Detect3d.inference_forward_feat)
+_LEVEL_STREAMS: list = []
+
+
+def level_streams(n: int):
+    while len(_LEVEL_STREAMS) < n:
+        _LEVEL_STREAMS.append(torch.cuda.Stream())
+    return _LEVEL_STREAMS[:n]
 _PLACE = None
 
 
