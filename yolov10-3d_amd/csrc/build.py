@@ -4,7 +4,7 @@ One hipcc -c per source (in parallel, cached by mtime), then one link.  No torch
 library is a plain C-ABI shared object (include/y3d.h).  Every compile also records the compiler's
 per-kernel resource report (`-Rpass-analysis=kernel-resource-usage`) next to the object:
 `resource_usage()` returns it, and tests/test_abi.py fails the build when a conv / attention kernel
-needs scratch (a spill inside those pipelines drains the LDS-DMA prefetch: conv3x3_wide.hip header)."""
+needs scratch (a spill inside those pipelines drains the LDS-DMA prefetch: conv3x3_wide3.hip header)."""
 import concurrent.futures as cf
 import os
 import re
