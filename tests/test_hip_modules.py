@@ -1220,6 +1220,8 @@ def test_graphed_eval_forward_replays_the_eager_forward():
     with torch.no_grad():
         eager = [[t.clone() for t in fwd(im)] for im in imgs]
     g = GraphedForward(fwd, imgs[0])
+    # inside the capture the three detection levels were recorded as parallel branches (modules.v10Detect3d.inference_forward_feat)
+    assert ops.EVAL_LEVEL_STREAMS and len(ops._LEVEL_STREAMS) >= model.model[-1].nl
     for im, ref in zip(imgs + imgs[:1], eager + eager[:1]):
         out = g(im)
         torch.cuda.synchronize()
