@@ -112,6 +112,9 @@ int y3d_set_tile_kernels(int enable);
 int y3d_set_stream1x1(int enable);
 int y3d_get_stream1x1(void);
 int y3d_get_tile_kernels(void);
+/* same for the row-wide workgroup slabs of the BatchNorm forward / backward-apply passes on bf16 tensors with >= 512 channels
+ * (bn_act.hip: slab_width) */
+int y3d_set_bn_wide_slabs(int enable);
 /* grad_oihw (+)= dL/dw.  Cin may be channel-padded (stem): only the first Cin_real channels are written. */
 int y3d_conv2d_bwd_weight(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int Cin,
                           int Cin_real, const void* dy, int64_t dsw, int Ho, int Wo, int Cout, int groups, int kh, int kw,

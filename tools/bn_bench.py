@@ -11,7 +11,7 @@ y3d = importlib.import_module("yolov10-3d_amd")
 ops = importlib.import_module("yolov10-3d_amd.ops")
 DEV = torch.device("cuda:0")
 BF16 = 1
-SHAPES = [(320, 32), (160, 64), (160, 32), (80, 128), (80, 64), (80, 256), (40, 256), (40, 128), (40, 512), (20, 512), (20, 256), (80, 2048)]
+SHAPES = [(320, 32), (160, 64), (160, 32), (80, 128), (80, 64), (80, 256), (40, 256), (40, 128), (40, 512), (20, 512), (20, 256), (80, 2048), (40, 2048), (20, 2048), (40, 1152), (80, 896)]
 
 
 def timeit(fn, reps):
@@ -60,4 +60,10 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "ab":  # row-wide slabs off / on (bn_act.hip: slab_width)
+        y3d.lib().set_bn_wide_slabs(0)
+        print("---- 64-channel slabs everywhere")
+        main()
+        y3d.lib().set_bn_wide_slabs(1)
+        print("---- row-wide slabs for bf16, C >= 512")
     main()

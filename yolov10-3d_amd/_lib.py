@@ -45,7 +45,7 @@ def parse_header(path: str = HEADER):
 
 
 # functions whose int return value is a result, not a status
-_PLAIN_INT = {"abi_version", "conv_kpad", "conv_stat_blocks", "conv2d_stat_rows", "conv2d_wgrad_splits", "conv2d_wgrad_plan", "set_tile_kernels", "set_stream1x1", "get_stream1x1", "get_tile_kernels", "dw_blocks", "dw_wgrad_blocks", "bn_bwd_blocks", "proj_blocks", "proj_group_blocks", "proj_group_bn_bwd_blocks", "proj_group_bwd_weight_bn_mfma_blocks", "tal3d_scratch_floats", "v10_postprocess_scratch_floats", "conv2d_fwd_affine_res_ok", "stem_conv_train_rows", "conv3x3_fp8_ok", "conv3x3_fp8_stat_rows", "fp8_scale_pitch"}
+_PLAIN_INT = {"abi_version", "conv_kpad", "conv_stat_blocks", "conv2d_stat_rows", "conv2d_wgrad_splits", "conv2d_wgrad_plan", "set_tile_kernels", "set_stream1x1", "set_bn_wide_slabs", "get_stream1x1", "get_tile_kernels", "dw_blocks", "dw_wgrad_blocks", "bn_bwd_blocks", "proj_blocks", "proj_group_blocks", "proj_group_bn_bwd_blocks", "proj_group_bwd_weight_bn_mfma_blocks", "tal3d_scratch_floats", "v10_postprocess_scratch_floats", "conv2d_fwd_affine_res_ok", "stem_conv_train_rows", "conv3x3_fp8_ok", "conv3x3_fp8_stat_rows", "fp8_scale_pitch"}
 
 
 class _Lib:

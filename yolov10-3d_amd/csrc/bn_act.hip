@@ -77,15 +77,16 @@ __global__ void bn_eval_scale_kernel(int C, const float* __restrict__ gamma, con
 template <typename T, int ACT, int RES>  // RES: 0 none, 1 post-activation, 2 pre-activation
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, long ysw, const float* __restrict__ scale,
                                   const float* __restrict__ shift, const T* __restrict__ res, long rsw, T* __restrict__ z, long zsw, long P,
-                                  int C, int px_per_block) {
-  // channel-stationary: a block owns a 64-channel slab and a run of pixels, scale/shift live in registers, two pixels in flight
+                                  int C, int px_per_block, int slabw) {
+  // channel-stationary: a block owns a slab of `slabw` channels (64, or up to the whole pixel row: slab_width) and a run of pixels,
+  // scale/shift live in registers, two pixels in flight
   constexpr int CE = TT<T>::CE;
   // a slab narrower than 64 channels (C = 32, or the last slab of C = 96) spends its spare chunk-threads on more pixels: with a
   // fixed 8 chunk-threads the 32-channel tensors of the first two stages ran with half of every wave idle (2.8-3.8 TB/s)
-  const int left = (C - (int)blockIdx.y * 64) / CE;
-  const int CT = left < 64 / CE ? left : 64 / CE, PT = 256 / CT;
+  const int left = (C - (int)blockIdx.y * slabw) / CE;
+  const int CT = left < slabw / CE ? left : slabw / CE, PT = 256 / CT;
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
-  const int c = blockIdx.y * 64 + ct * CE;
+  const int c = blockIdx.y * slabw + ct * CE;
   if (pt >= PT) return;
   float sc[CE], sf[CE];
 #pragma unroll
@@ -163,14 +164,15 @@ template <typename T, int ACT, int RES>
 __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
                                          const T* __restrict__ res, long rsw, const float* __restrict__ scale,
                                          const float* __restrict__ shift, const float* __restrict__ mean,
-                                         const float* __restrict__ invstd, float* __restrict__ part, long P, int C, int px_per_block) {
+                                         const float* __restrict__ invstd, float* __restrict__ part, long P, int C, int px_per_block,
+                                         int slabw) {
   constexpr int CE = TT<T>::CE;
-  // chunk-threads per slab: 64 / CE, fewer when the slab is narrower (see bn_act_fwd_kernel); the rest are pixel-threads
-  const int left = (C - (int)blockIdx.y * 64) / CE;
-  const int CT = left < 64 / CE ? left : 64 / CE, PT = 256 / CT, SW = CT * CE;
-  __shared__ float sh[256 / (64 / CE) * 64 * 2];  // [PT][SW][2]: PT * SW <= 256 * CE
+  // chunk-threads per slab: slabw / CE, fewer when the slab is narrower (see bn_act_fwd_kernel); the rest are pixel-threads
+  const int left = (C - (int)blockIdx.y * slabw) / CE;
+  const int CT = left < slabw / CE ? left : slabw / CE, PT = 256 / CT, SW = CT * CE;
+  __shared__ float sh[256 * CE * 2];  // [PT][SW][2]: PT * SW <= 256 * CE
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
-  const int c = blockIdx.y * 64 + ct * CE;
+  const int c = blockIdx.y * slabw + ct * CE;
   float s1[CE], s2[CE];
 #pragma unroll
   for (int j = 0; j < CE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -217,13 +219,12 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, cons
     for (int j = 0; j < CE; ++j) { sh[(pt * SW + ct * CE + j) * 2] = s1[j]; sh[(pt * SW + ct * CE + j) * 2 + 1] = s2[j]; }
   }
   __syncthreads();
-  if (threadIdx.x < SW) {
-    int cc = blockIdx.y * 64 + threadIdx.x;
+  for (int t = threadIdx.x; t < SW; t += 256) {
+    int cc = blockIdx.y * slabw + t;
     if (cc < C) {
       float a = 0.f, b = 0.f;
-      for (int r = 0; r < PT; ++r) { a += sh[(r * SW + threadIdx.x) * 2]; b += sh[(r * SW + threadIdx.x) * 2 + 1]; }
-      part[((long)blockIdx.x * C + cc) * 2] = a;
-      part[((long)blockIdx.x * C + cc) * 2 + 1] = b;
+      for (int r = 0; r < PT; ++r) { a += sh[(r * SW + t) * 2]; b += sh[(r * SW + t) * 2 + 1]; }
+      *(float2*)(part + ((long)blockIdx.x * C + cc) * 2) = make_float2(a, b);
     }
   }
 }
@@ -276,12 +277,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                         const float* __restrict__ shift, const float* __restrict__ mean,
                                         const float* __restrict__ invstd, const float* __restrict__ mg,
                                         const float* __restrict__ mgx, T* __restrict__ dy, long dysw, T* __restrict__ dres,
-                                        long drsw, long P, int C, int px_per_block) {
+                                        long drsw, long P, int C, int px_per_block, int slabw) {
   constexpr int CE = TT<T>::CE;
-  const int left = (C - (int)blockIdx.y * 64) / CE;
-  const int CT = left < 64 / CE ? left : 64 / CE, PT = 256 / CT;  // chunk-threads per slab, pixel-threads (see bn_act_fwd_kernel)
+  const int left = (C - (int)blockIdx.y * slabw) / CE;
+  const int CT = left < slabw / CE ? left : slabw / CE, PT = 256 / CT;  // chunk-threads per slab, pixel-threads (see bn_act_fwd_kernel)
   const int ct = threadIdx.x % CT, pt = threadIdx.x / CT;
-  const int c = blockIdx.y * 64 + ct * CE;
+  const int c = blockIdx.y * slabw + ct * CE;
   if (pt >= PT) return;
   // dy = a * g + b * y + k   with  a = scale, b = -scale * invstd^2... kept explicit for exactness with the reference formula
   float sc[CE], sf[CE], mu[CE], is[CE], m1[CE], m2[CE];
@@ -352,12 +353,33 @@ __global__ void colsum_kernel(const T* __restrict__ x, long xsw, float* __restri
   }
 }
 
-// ~8 workgroups per CU as (pixel runs) x (64-channel slabs); a run is at least 64 pixels
-inline dim3 slab_grid(long P, int C, int* ppb) {
-  const int nslab = cdiv(C, 64);
+// Channels of a pixel row one workgroup covers.  64 (a wave instruction = eight 128-byte pieces, one pixel pitch apart) streams the narrow
+// tensors at 5.5-6.5 TB/s, but the 2048-channel head tensors (839 MB at stride 8) at 4.1 / 4.2 TB/s forward / apply in a stand-alone probe:
+// there a workgroup takes the WHOLE 4 KB row and walks consecutive pixels - one contiguous stream per workgroup - 5.0-5.4 / 5.1-5.4 TB/s
+// (tools/probe/bn_stream_probe.cpp, profiles/r04_bn_stream_probe.txt; these kernels, tools/bn_bench.py ab, profiles/r04_bn_bench_ab.txt:
+// forward 377 -> 339 us, apply 631 -> 499 us on the stride-8 tensor (548 -> 474 on another box), 98 -> 87 and 163 -> 127 us at stride 16; the reduce pass does not
+// gain, y3d_bn_bwd_blocks).  bf16, C >= 512: the row, or the largest whole fraction of it that keeps >= 84 % of the 256 threads busy
+// (chunk-threads x pixel-threads).
+int g_wide_slabs = 1;
+
+inline int slab_width(int dtype, int C) {
+  if (!g_wide_slabs || dtype != Y3D_BF16 || C < 512) return 64;
+  for (int k = 1; k <= 8; ++k) {
+    if (C % k != 0 || (C / k) % 8 != 0) continue;
+    const int ct = C / k / 8;
+    if (ct > 256) continue;
+    if (ct * (256 / ct) >= 216) return C / k;
+  }
+  return 64;
+}
+
+// ~8 workgroups per CU as (pixel runs) x (slabs); every pixel-thread of a run has at least two pixels
+inline dim3 slab_grid(long P, int C, int* ppb, int slabw = 64, int ce = 8) {
+  const int nslab = cdiv(C, slabw);
+  const int ct = (C < slabw ? C : slabw) / ce, minrun = slabw == 64 ? 64 : 2 * (256 / ct);
   long npx = 2048 / nslab;
   if (npx < 1) npx = 1;
-  if (npx > (P + 63) / 64) npx = (P + 63) / 64;
+  if (npx > (P + minrun - 1) / minrun) npx = (P + minrun - 1) / minrun;
   *ppb = (int)((P + npx - 1) / npx);
   return dim3((unsigned)npx, nslab);
 }
@@ -371,10 +393,11 @@ template <typename T, int ACT>
 int launch_fwd(int res_mode, const void* y, long ysw, const float* scale, const float* shift, const void* res, long rsw,
                void* z, long zsw, long P, int C, hipStream_t st) {
   int ppb;
-  dim3 g = slab_grid(P, C, &ppb), b(256);
-  if (res_mode == 0) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 0>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb);
-  else if (res_mode == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 1>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb);
-  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 2>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb);
+  const int sw = slab_width(TT<T>::CE == 8 ? Y3D_BF16 : Y3D_F32, C);
+  dim3 g = slab_grid(P, C, &ppb, sw, TT<T>::CE), b(256);
+  if (res_mode == 0) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 0>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb, sw);
+  else if (res_mode == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 1>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb, sw);
+  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, 2>), g, b, 0, st, (const T*)y, ysw, scale, shift, (const T*)res, rsw, (T*)z, zsw, P, C, ppb, sw);
   Y3D_LAUNCH_CHECK();
   return Y3D_OK;
 }
@@ -382,6 +405,12 @@ int launch_fwd(int res_mode, const void* y, long ysw, const float* scale, const 
 }  // namespace
 
 extern "C" {
+
+int y3d_set_bn_wide_slabs(int enable) {
+  const int old = g_wide_slabs;
+  g_wide_slabs = enable ? 1 : 0;
+  return old;
+}
 
 int y3d_bn_finalize(const float* partials, int nblk, int C, int64_t count, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
@@ -438,6 +467,8 @@ int y3d_bn_bwd_blocks(int64_t P, int C) {
   // pixel runs of >= 128 pixels; (runs) x (64-channel slabs) ~ 8 workgroups per CU, at most 2048 rows for the finalize pass.  (Runs of
   // >= 512 pixels left the 20x20 / 40x40 tensors with 200 workgroups of 16 dependent pixel steps each: 15-17 us for 13 MB, twice the
   // apply pass that writes as well.)
+  // The reduce pass keeps 64-channel slabs on every tensor: row-wide slabs (slab_width) in 1024 runs measured 353 against 350 us on the 839 MB
+  // head tensor and 172 against 159 us on 204 800 x 896 (tools/bn_bench.py ab) - its two read streams already run at 4.8 TB/s.
   long n = (P + 127) / 128;
   long cap = 2048 / cdiv(C, 64);
   if (cap < 64) cap = 64;
@@ -447,7 +478,7 @@ int y3d_bn_bwd_blocks(int64_t P, int C) {
 
 #define BWD_REDUCE(T, A, R)                                                                                                  \
   hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, A, R>), grid, dim3(256), 0, st, (const T*)y, ysw, (const T*)dz, dsw,        \
-                     (const T*)res, rsw, scale, shift, mean, invstd, partials, (long)P, C, ppb)
+                     (const T*)res, rsw, scale, shift, mean, invstd, partials, (long)P, C, ppb, sw)
 
 int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz, int64_t dsw, const void* res, int64_t rsw,
                           const float* scale, const float* shift, const float* mean, const float* invstd, int act,
@@ -456,7 +487,8 @@ int y3d_bn_act_bwd_reduce(int dtype, const void* y, int64_t ysw, const void* dz,
       ew_check("bn_act_bwd_reduce res", dtype, res, rsw, C)) return Y3D_ERR_INVALID;
   int nblk = y3d_bn_bwd_blocks(P, C);
   int ppb = (int)((P + nblk - 1) / nblk);
-  dim3 grid(nblk, cdiv(C, 64));
+  const int sw = 64;  // see y3d_bn_bwd_blocks
+  dim3 grid(nblk, cdiv(C, sw));
   hipStream_t st = (hipStream_t)stream;
   int r2 = (res_mode == 2 && act) ? 2 : 0;
   if (dtype == Y3D_BF16) {
@@ -480,7 +512,7 @@ int y3d_bn_bwd_finalize(const float* partials, int nblk, int C, int64_t count, f
 
 #define BWD_APPLY(T, A, R, TR)                                                                                               \
   hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, A, R, TR>), grid, dim3(256), 0, st, (const T*)y, ysw, (const T*)dz, dsw,    \
-                     (const T*)res, rsw, scale, shift, mean, invstd, mean_g, mean_gx, (T*)dy, dysw, (T*)dres, drsw, (long)P, C, ppb)
+                     (const T*)res, rsw, scale, shift, mean, invstd, mean_g, mean_gx, (T*)dy, dysw, (T*)dres, drsw, (long)P, C, ppb, sw)
 #define BWD_APPLY_T(T)                                                        \
   do {                                                                        \
     if (train) {                                                              \
@@ -501,7 +533,8 @@ int y3d_bn_act_bwd_apply(int dtype, const void* y, int64_t ysw, const void* dz, 
       ew_check("bn_act_bwd_apply dres", dtype, dres, drsw, C)) return Y3D_ERR_INVALID;
   int r2 = res_mode == 2 ? 2 : 0;
   int ppb;
-  dim3 grid = slab_grid(P, C, &ppb);
+  const int sw = slab_width(dtype, C);
+  dim3 grid = slab_grid(P, C, &ppb, sw, dtype == Y3D_BF16 ? 8 : 4);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == Y3D_BF16) BWD_APPLY_T(bf16_t); else BWD_APPLY_T(float);
   Y3D_LAUNCH_CHECK();
