@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_q_kernel(const bf16_t* __restr
 // backward pass 1: g = dz * act'(u); per-block partial sums of g and g*xhat.
 // Block = 256 threads = (64/CE... ) organised as CT chunk-threads x PT pixel-threads over a 64-channel slab.
 template <typename T, int ACT, int RES>
-__global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ y, long ysw, const T* __restrict__ dz, long dsw,
                                          const T* __restrict__ res, long rsw, const float* __restrict__ scale,
                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                          const float* __restrict__ invstd, float* __restrict__ part, long P, int C, int px_per_block,
