@@ -308,15 +308,28 @@ def main(argv=None):
             # rank 0 prints the line with the eager rate and every rank leaves
             import threading
 
-            def bail():
-                if rank == 0:
-                    print(json.dumps({"metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            def eager_line():
+                return json.dumps({"metric": "train_images_per_sec", "value": round(train_ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                                       "warmup": args.warmup, "ms_per_step": round(1e3 * world * B / train_ips, 3), "higher_is_better": True, "scaling": "weak",
                                       "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                                       "config": {"workload": f"{args.model}, {S}x{S}, {args.dtype}, batch {B}/GPU, train step = fwd+loss+bwd+clip+SGD+EMA",
                                                  "global_batch": world * B, "imgsz": S, "parallelism": f"dp{world}"},
-                                      "train_mode": "eager", "note": "the hipGraph leg of the data-parallel step did not finish within 240 s: eager rate only"}), flush=True)
+                                      "train_mode": "eager", "note": "the hipGraph leg of the data-parallel step did not finish (240 s limit or a fatal signal): eager rate only"})
+
+            def bail():
+                if rank == 0:
+                    print(eager_line(), flush=True)
                 os._exit(0)
+            # ... and a leg that KILLS the process (a fatal signal inside the capture) must not either: tools/crash_line.c prints the same line
+            # from the signal handler on rank 0 and leaves quietly on the others
+            crash_guard = None
+            try:
+                import ctypes
+                crash_guard = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "libcrash_line.so"))
+                sys.stdout.flush()
+                crash_guard.crash_line_arm(eager_line().encode() if rank == 0 else b"", 0)
+            except OSError:
+                crash_guard = None
             watchdog = threading.Timer(240.0, bail)
             watchdog.daemon = True
             watchdog.start()
@@ -348,6 +361,8 @@ def main(argv=None):
             log(f"hipGraph capture of the training step failed ({type(e).__name__}: {e})")
         if watchdog is not None:
             watchdog.cancel()
+            if crash_guard is not None:
+                crash_guard.crash_line_disarm()
 
     # inference leg: eval forward + NMS-free top-k postprocess (reference validator.py:178,190: "Speed: ... ms per image").  The forward
     # is ~200 launches of 3-150 us: enqueued eagerly the host is the bound (tools/eval_audit.py), so the timed loop replays ONE captured

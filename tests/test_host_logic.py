@@ -244,3 +244,28 @@ def test_dropin_against_the_reference():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     last = json.loads(r.stdout.strip().splitlines()[-1])
     assert last == {"yamls": 12, "failed": 0}
+
+
+def test_bench_crash_guard_prints_the_measured_line(tmp_path):
+    """tools/crash_line.c (bench.py, N > 1 hipGraph leg): a fatal signal after arming prints the preformatted line from the handler and
+    exits with the given code; disarmed, the default action is back"""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libcrash_line.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-Werror", os.path.join(root, "tools", "crash_line.c"), "-o", so], check=True)
+    prog = textwrap.dedent(f"""
+        import ctypes, sys
+        L = ctypes.CDLL({so!r})
+        assert L.crash_line_arm(b'{{"metric": "m", "value": 1.5}}', 0) == 0
+        if sys.argv[1] == "disarm":
+            L.crash_line_disarm()
+        sys.stdout.flush()
+        ctypes.string_at(0)
+    """)
+    r = subprocess.run([sys.executable, "-c", prog, "armed"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == '{"metric": "m", "value": 1.5}\n'
+    r = subprocess.run([sys.executable, "-c", prog, "disarm"], capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout == ""
