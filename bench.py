@@ -150,8 +150,8 @@ def log(msg):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolov10s_3D.yaml")
@@ -162,7 +162,7 @@ def main(argv=None):
                     help="with --weights fp8: keep every convolution on the bf16 matrix cores (fp8-VALUED weights only: the round-3 form), for A/B runs "
                          "against the fp8 MFMA convolutions (csrc/conv3x3_fp8.hip) that --weights fp8 turns on by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--infer-steps", type=int, default=10)
+    ap.add_argument("--infer-steps", type=int, default=40)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--phases", action="store_true", help="per-phase device times (backward / all-reduce / optimizer) in the JSON line (default for N > 1)")

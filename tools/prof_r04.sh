@@ -10,7 +10,7 @@ export Y3D_COMMIT=${2:-r04}
 cd /tmp && export TMPDIR=/tmp
 case $PART in
 bench)
-  python3 $R/bench.py > $O/${T}_bench_default.log 2>&1
+  python3 $R/bench.py > $O/${T}_bench_default.log 2>&1   # defaults: 100 timed steps, 10 warm-up, 40 eval batches
   python3 $R/bench.py --steps 300 --warmup 5 --no-cpu-baseline --infer-steps 2 > $O/${T}_bench_300steps.log 2>&1
   tail -1 $O/${T}_bench_default.log | cut -c1-300; tail -1 $O/${T}_bench_300steps.log | cut -c1-300 ;;
 stats)
