@@ -129,6 +129,12 @@ int y3d_dw_pack_weight(const float* w_oihw, float* out_taps_c, int C, int kh, in
 int y3d_dwconv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
                      const float* w_packed, void* y, int64_t ysw, int Ho, int Wo, int kh, int kw, int stride, int pad,
                      float* stat_partials, void* stream);
+/* eval: z = act(dwconv(x) * scale[c] + shift[c] (+ res, res_mode 2)) (+ res, res_mode 1) in one launch - the folded BatchNorm + SiLU (+ the
+ * RepVGGDW / shortcut residual, block.py:711, 758) applied to the depth-wise result rounded as y3d_dwconv2d_fwd would have stored it, so the
+ * values are those of y3d_dwconv2d_fwd + y3d_bn_act_fwd bit for bit */
+int y3d_dwconv2d_fwd_affine(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
+                            const float* w_packed, const float* scale, const float* shift, int act, int res_mode, const void* res, int64_t rsw,
+                            void* z, int64_t zsw, int Ho, int Wo, int kh, int kw, int stride, int pad, void* stream);
 int y3d_dwconv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, int64_t dsw, int B, int Ho, int Wo, int C,
                           const float* w_packed, void* dx, int64_t xsw, int H, int W, int kh, int kw, int stride, int pad,
                           void* stream);

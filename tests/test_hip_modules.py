@@ -1501,3 +1501,41 @@ def test_autocast_and_gradscaler_leave_the_step_unchanged():
     scaler.step(opt)
     scaler.update()
     assert scaler.get_scale() == 1024.0  # no inf / NaN found: the scale is kept
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_depthwise_eval_epilogue_is_the_two_pass_form_bit_for_bit(dtype):
+    """csrc/dwconv.hip: y3d_dwconv2d_fwd_affine (eval: depth-wise conv + folded BatchNorm + SiLU + residual in ONE launch) applies the
+    affine pass to the conv result rounded as the pre-BatchNorm tensor would have been stored, so it must equal y3d_dwconv2d_fwd +
+    y3d_bn_act_fwd (`ops.DW_EVAL_FUSED = False`) exactly: depth-wise Conv k3 / k3 s2 without activation (SCDown, block.py:824) / k7,
+    RepVGGDW (pre-activation residual, block.py:711) and a whole C2fCIB with `lk=True` (block.py:737-768)"""
+    from yolov10_3d_amd import ops
+    y3d.set_compute_dtype(dtype)
+    torch.manual_seed(5)
+    mods = [M.Conv(64, 64, 3, 1, g=64), M.Conv(96, 96, 3, 2, g=96, act=False), M.Conv(64, 64, 7, 1, g=64, act=False), M.RepVGGDW(64),
+            M.C2fCIB(64, 64, 1, True, True), M.SCDown(64, 128, 3, 2)]
+    shapes = [(2, 64, 20, 24), (2, 96, 21, 19), (2, 64, 20, 20), (2, 64, 12, 20), (2, 64, 16, 16), (2, 64, 16, 24)]
+    old = ops.DW_EVAL_FUSED
+    try:
+        for m, shp in zip(mods, shapes):
+            m = m.to(DEV)
+            for b in m.modules():
+                if isinstance(b, torch.nn.BatchNorm2d):
+                    with torch.no_grad():
+                        b.running_mean.uniform_(-0.3, 0.3)
+                        b.running_var.uniform_(0.5, 1.5)
+                        b.weight.uniform_(0.5, 1.5)
+                        b.bias.uniform_(-0.2, 0.2)
+            m.eval()
+            x = torch.randn(*shp, device=DEV)
+            outs = []
+            for flag in (True, False):
+                ops.DW_EVAL_FUSED = flag
+                with torch.no_grad():
+                    outs.append(m(x).float().clone())
+            assert torch.equal(outs[0], outs[1]), f"{type(m).__name__} {shp}: fused depth-wise epilogue differs from conv + bn_act_fwd"
+            assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+    finally:
+        ops.DW_EVAL_FUSED = old
+        y3d.set_compute_dtype(torch.float32)

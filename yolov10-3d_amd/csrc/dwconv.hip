@@ -30,11 +30,17 @@ struct DwP {
   int B, Hg, Wg, Hq, Wq, C, kh, kw, stride, pad;
   long M;
   int px_per_block;
+  // eval epilogue (AFF): z = act(y * scale[c] + shift[c] (+ res if res_mode 2)) (+ res if res_mode 1) - the folded BatchNorm + SiLU + residual
+  // that y3d_bn_act_fwd would apply in a second pass, on the value ROUNDED as the pre-BatchNorm tensor would have been stored
+  const float *scale, *shift;
+  const void* res;
+  long rsw;
+  int act, res_mode;
 };
 
 // K = 3 / 7: the filter rows are unrolled and a row's K loads are issued together (predicated, zero outside the map); with runtime
 // tap loops every load waited for the previous one (1 TB/s on the 3x3 layers).  K = 0: any filter size (runtime loops).
-template <typename T, bool DGRAD, int K>
+template <typename T, bool DGRAD, int K, bool AFF = false>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
   constexpr int CE = TT<T>::CE;
   constexpr int CT = 64 / CE;
@@ -56,6 +62,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
   float s1[CE], s2[CE];
 #pragma unroll
   for (int j = 0; j < CE; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  float esc[CE], esf[CE];
+  if (AFF && c < p.C) {
+#pragma unroll
+    for (int j = 0; j < CE; ++j) { esc[j] = p.scale[c + j]; esf[j] = p.shift[c + j]; }
+  }
   if (c < p.C) {
     long pbeg = (long)blockIdx.x * p.px_per_block;
     long pend = pbeg + p.px_per_block < p.M ? pbeg + p.px_per_block : p.M;
@@ -143,6 +154,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwP p) {
         acc[j] = TT<T>::rnd(acc[j]);
         s1[j] += acc[j];
         s2[j] += acc[j] * acc[j];
+      }
+      if (AFF) {
+        float r[CE];
+        if (p.res_mode) Chunk<T>::unpack(*(const uint4*)((const T*)p.res + m * p.rsw + c), r);
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+          float u = acc[j] * esc[j] + esf[j];
+          if (p.res_mode == 2) u += r[j];
+          if (p.act) u = silu_f(u);
+          if (p.res_mode == 1) u += r[j];
+          acc[j] = u;
+        }
       }
       *(uint4*)(Y + m * p.ysw + c) = Chunk<T>::pack(acc);
     }
@@ -330,10 +353,12 @@ int y3d_dw_pack_weight(const float* w_oihw, float* out, int C, int kh, int kw, v
 }
 
 #define DW_LAUNCH_K(T, D, K) hipLaunchKernelGGL((dwconv_kernel<T, D, K>), grid, dim3(256), sm, st, p)
+#define DW_LAUNCH_A(T, K) hipLaunchKernelGGL((dwconv_kernel<T, false, K, true>), grid, dim3(256), sm, st, p)
 #define DW_LAUNCH(T)                                                                                             \
   do {                                                                                                           \
     const int kk = (p.kh == p.kw && (p.kh == 3 || p.kh == 7)) ? p.kh : 0;                                        \
-    if (dgrad) { if (kk == 3) DW_LAUNCH_K(T, true, 3); else if (kk == 7) DW_LAUNCH_K(T, true, 7); else DW_LAUNCH_K(T, true, 0); }     \
+    if (!dgrad && p.scale) { if (kk == 3) DW_LAUNCH_A(T, 3); else if (kk == 7) DW_LAUNCH_A(T, 7); else DW_LAUNCH_A(T, 0); }           \
+    else if (dgrad) { if (kk == 3) DW_LAUNCH_K(T, true, 3); else if (kk == 7) DW_LAUNCH_K(T, true, 7); else DW_LAUNCH_K(T, true, 0); }     \
     else { if (kk == 3) DW_LAUNCH_K(T, false, 3); else if (kk == 7) DW_LAUNCH_K(T, false, 7); else DW_LAUNCH_K(T, false, 0); }        \
   } while (0)
 
@@ -362,7 +387,29 @@ int y3d_dwconv2d_fwd(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t
   Y3D_CHECK((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && xsb % ce == 0 && xsh % ce == 0 && xsw % ce == 0 && ysw % ce == 0, "dwconv2d_fwd: alignment");
   DwP p;
   p.x = x; p.w = w_packed; p.y = y; p.part = stat_partials;
+  p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.rsw = 0; p.act = 0; p.res_mode = 0;
   p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = ysw;
+  p.B = B; p.Hg = H; p.Wg = W; p.Hq = Ho; p.Wq = Wo; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+  p.M = (long)B * Ho * Wo;
+  int nblk = y3d_dw_blocks(p.M);
+  p.px_per_block = (int)((p.M + nblk - 1) / nblk);
+  return dw_launch(dtype, false, p, (hipStream_t)stream);
+}
+
+int y3d_dwconv2d_fwd_affine(int dtype, const void* x, int64_t xsb, int64_t xsh, int64_t xsw, int B, int H, int W, int C,
+                            const float* w_packed, const float* scale, const float* shift, int act, int res_mode, const void* res, int64_t rsw,
+                            void* z, int64_t zsw, int Ho, int Wo, int kh, int kw, int stride, int pad, void* stream) {
+  int ce = dtype == Y3D_BF16 ? 8 : 4;
+  Y3D_CHECK(dtype == Y3D_BF16 || dtype == Y3D_F32, "dwconv2d_fwd_affine: bad dtype");
+  Y3D_CHECK(C % ce == 0, "dwconv2d_fwd_affine: C=%d not a multiple of %d", C, ce);
+  Y3D_CHECK(Ho == (H + 2 * pad - kh) / stride + 1 && Wo == (W + 2 * pad - kw) / stride + 1, "dwconv2d_fwd_affine: output dims");
+  Y3D_CHECK((((uintptr_t)x | (uintptr_t)z) & 15) == 0 && xsb % ce == 0 && xsh % ce == 0 && xsw % ce == 0 && zsw % ce == 0, "dwconv2d_fwd_affine: alignment");
+  Y3D_CHECK(scale && shift && res_mode >= 0 && res_mode <= 2, "dwconv2d_fwd_affine: scale / shift missing or bad residual mode");
+  Y3D_CHECK(res_mode == 0 || (res && (((uintptr_t)res) & 15) == 0 && rsw % ce == 0), "dwconv2d_fwd_affine: residual missing or misaligned");
+  DwP p;
+  p.x = x; p.w = w_packed; p.y = z; p.part = nullptr;
+  p.scale = scale; p.shift = shift; p.res = res; p.rsw = rsw; p.act = act; p.res_mode = res_mode;
+  p.xsb = xsb; p.xsh = xsh; p.xsw = xsw; p.ysw = zsw;
   p.B = B; p.Hg = H; p.Wg = W; p.Hq = Ho; p.Wq = Wo; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.M = (long)B * Ho * Wo;
   int nblk = y3d_dw_blocks(p.M);
@@ -379,6 +426,7 @@ int y3d_dwconv2d_bwd_data(int dtype, const void* dy, int64_t dsb, int64_t dsh, i
   Y3D_CHECK((((uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && dsb % ce == 0 && dsh % ce == 0 && dsw % ce == 0 && xsw % ce == 0, "dwconv2d_bwd_data: alignment");
   DwP p;
   p.x = dy; p.w = w_packed; p.y = dx; p.part = nullptr;
+  p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.rsw = 0; p.act = 0; p.res_mode = 0;
   p.xsb = dsb; p.xsh = dsh; p.xsw = dsw; p.ysw = xsw;
   p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hq = H; p.Wq = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
   p.M = (long)B * H * W;

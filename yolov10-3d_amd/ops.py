@@ -503,6 +503,7 @@ def fp8_weight(ent, Cg):
 PROJ_BN_MFMA = True  # BatchNorm backward of the second head layer recomputing dz on MFMA (tests flip it: materialised path)
 STEM_FUSED = True  # the stem in one pass (tests flip it: im2col + dense conv)
 PACK_CACHE = True  # weight packs through the registry (one multi-tensor launch per step)
+DW_EVAL_FUSED = True  # eval depth-wise conv: folded BatchNorm + SiLU + residual in the conv's epilogue (tests flip it: conv + bn_act_fwd)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -652,7 +653,8 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
     else:
         xin = to_nhwc(x, dtype)
     sb, sh, sw = s3(xin)
-    y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev) if (dw or training or res_mode) else None  # pre-BatchNorm tensor (the eval fast path has none)
+    dw_fused = dw and not training and bn_apply and DW_EVAL_FUSED
+    y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev) if ((dw or training or res_mode) and not dw_fused) else None  # pre-BatchNorm tensor (the eval fast paths have none)
     part = None
     if dw:
         if Cout % c != 0:
@@ -666,6 +668,17 @@ def _cba_forward(x, w32, g32, b32, rm, rv, k, s, p, g, act, res, res_mode, train
             L.dw_pack_weight(w32.data_ptr(), wp.data_ptr(), Cout, k, k, st)
         else:
             wp, ss_eval = _eval_consts(cache, "dw", w32, g32, b32, rm, rv, ver, dtype, k, g, 1, 1, Cout, eps)
+            if dw_fused:
+                # eval: folded BatchNorm + SiLU (+ the RepVGGDW / shortcut residual) in the depth-wise kernel's epilogue - one launch, no
+                # pre-BN tensor (12 depth-wise layers of S-3D: 12 bn_act_fwd launches and their read + write less per forward)
+                ze = out_tensor(B, Cout, Ho, Wo, dtype, dev)
+                rr = to_nhwc(res, dtype, dense=True) if res_mode else None
+                if rr is not None:
+                    assert rr.shape == ze.shape, "residual shape mismatch"
+                L.dwconv2d_fwd_affine(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), ss_eval[0].data_ptr(), ss_eval[1].data_ptr(), int(act),
+                                      res_mode, rr.data_ptr() if rr is not None else None, rr.stride(3) if rr is not None else 0,
+                                      ze.data_ptr(), ze.stride(3), Ho, Wo, k, k, s, p, st)
+                return ze, None, None
         L.dwconv2d_fwd(dt, xin.data_ptr(), sb, sh, sw, B, H, W, Cin, wp.data_ptr(), y.data_ptr(), Cout, Ho, Wo, k, k, s, p,
                        part.data_ptr() if training else None, st)
     elif pre_conv is not None:  # the caller has run the conv (fused training stem): pre-BN tensor + BatchNorm partial rows
