@@ -43,20 +43,27 @@ template <int CB> __device__ __forceinline__ int sm_swz(int row) { return CB == 
 // (row & 1, column & 1) of the halo coordinate): tap (r, q) of output pixel (y, x) reads halo (2y + r, 2x + q) = plane (r & 1, q & 1),
 // position (y + (r >> 1), x + (q >> 1)) - sixteen consecutive lanes read sixteen consecutive pixels of one plane row, exactly the
 // stride-1 access pattern, with the same swizzle.  Only the slot -> source-pixel map of the DMA plan and the tap offsets differ.
-template <int CB, int NCT, bool AFF, int ST>  // NCT: 16-channel output tiles (Cout <= 16 NCT); AFF: folded BatchNorm + SiLU (+ residual) epilogue
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
+// NW = 8 (round 4, NCT even): eight waves share the 8 x 16 tile as 4 row pairs x 2 channel halves.  With four waves a SIMD holds ONE wave,
+// which reads its fragments, waits, multiplies, 18 times per tile: 12 700 cycles per tile at 64 -> 64 against 2 300 of MFMA work and 3 400 of
+// LDS reads.  Two waves per SIMD overlap one's LDS latency with the other's MFMAs (a wave then reads 2 + 2 fragments for 4 MFMAs instead of
+// 4 + 2 for 8: a third more LDS bytes, which is not the bound).  Same accumulation order per output: bit-identical results.
+template <int CB, int NCT, bool AFF, int ST, int NW>  // NCT: 16-channel output tiles (Cout <= 16 NCT); AFF: folded BatchNorm + SiLU (+ residual) epilogue
+__global__ __launch_bounds__(NW * 64) void conv3x3_small_kernel(SmP p) {
+  static_assert(NW == 4 || (NW == 8 && NCT % 2 == 0), "eight waves split the channel tiles in two halves");
+  constexpr int NT = NW * 64;                                   // threads
+  constexpr int NCW = NW == 8 ? NCT / 2 : NCT;                  // channel tiles per wave
   constexpr int TH = 8;
   constexpr int HW = ST == 1 ? 18 : 17;                         // pixels per row of a halo plane
   constexpr int PP = (ST == 1 ? TH + 2 : TH + 1) * HW;          // pixel slots per plane: 180 / 153
   constexpr int NPIX = ST == 1 ? PP : 4 * PP;                   // 180 halo pixels / 612 slots (561 real ones)
   constexpr int SPI = 1024 / CB;                                // pixel slots per DMA instruction (8 or 16)
   constexpr int NINST = (NPIX + SPI - 1) / SPI;                 // 23 / 12
-  constexpr int NI = (NINST + 3) / 4;                           // per wave (the last ones may be dummies into the slack)
-  constexpr int TILE = NI * 4 * 1024;                           // bytes per halo buffer
+  constexpr int NI = (NINST + NW - 1) / NW;                     // per wave (the last ones may be dummies into the slack)
+  constexpr int TILE = NI * NW * 1024;                          // bytes per halo buffer
   constexpr int KS = CB / 64;                                   // 32-channel MFMA steps per tap
   constexpr int CPR = CB / 16;                                  // chunks per row
   constexpr int WB = 9 * NCT * 16 * CB;                         // resident weights [tap][co][CB]
-  constexpr int NST = 2 * NCT;                                  // stores per wave per tile
+  constexpr int NST = 2 * NCW;                                  // stores per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;
   char* sH = smem + WB;
@@ -64,7 +71,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   const int nwk = gridDim.x, wk = blockIdx.x;
   const int Cin = p.Cin;  // <= CB / 2: the chunks of an LDS row past the real channels hold zeros (weights: below; halo: out-of-range DMA lanes)
 
-  for (int i = tid; i < 9 * NCT * 16 * CPR; i += 256) {
+  const int wr = wave & 3, wc = wave >> 2;  // row pair of the tile, channel half (NW = 8)
+  for (int i = tid; i < 9 * NCT * 16 * CPR; i += NT) {
     const int c = i % CPR, r = (i / CPR) % (NCT * 16), tap = i / (CPR * NCT * 16);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r < p.Cout && c * 8 < Cin) v = *(const uint4*)(p.w + (long)r * p.Ktot + (p.flip ? 8 - tap : tap) * Cin + c * 8);
@@ -116,20 +124,20 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   if (wk < p.ntiles) issue(wk, 0);
 
   const int lp = lane & 15, lq = lane >> 4;
-  float ssum[NCT][4], ssq[NCT][4];
+  float ssum[NCW][4], ssq[NCW][4];
 #pragma unroll
-  for (int a = 0; a < NCT; ++a)
+  for (int a = 0; a < NCW; ++a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
   // eval epilogue constants of this lane's channels (16 a + 4 lq + j), loaded ONCE: a load inside the tile loop makes the compiler wait
   // vmcnt(0) there and drains the halo prefetch of the next tile every tile (58 us against 33 us for the training form at 64 -> 64 @80x80)
-  float sv[AFF ? NCT : 1][4], hv[AFF ? NCT : 1][4];
+  float sv[AFF ? NCW : 1][4], hv[AFF ? NCW : 1][4];
   if (AFF) {
 #pragma unroll
-    for (int a = 0; a < NCT; ++a)
+    for (int a = 0; a < NCW; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int c = a * 16 + 4 * lq + j;
+        const int c = (wc * NCW + a) * 16 + 4 * lq + j;
         sv[a][j] = c < p.Cout ? p.scale[c] : 0.f;
         hv[a][j] = c < p.Cout ? p.shift[c] : 0.f;
       }
@@ -145,43 +153,43 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
     int b, y0, x0;
     decode(t, b, y0, x0);
     const char* hb = sH + buf * TILE;
-    f32x4_t acc[2][NCT];  // [row of the wave][output-channel tile]
+    f32x4_t acc[2][NCW];  // [row of the wave][output-channel tile of the wave]
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int a = 0; a < NCT; ++a) acc[r][a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < NCW; ++a) acc[r][a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int tr = tap / 3, tq = tap - tr * 3;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        bf16x8_t fa[NCT], fb[2];
+        bf16x8_t fa[NCW], fb[2];
 #pragma unroll
-        for (int a = 0; a < NCT; ++a) {
-          const int r = a * 16 + lp;
+        for (int a = 0; a < NCW; ++a) {
+          const int r = (wc * NCW + a) * 16 + lp;
           fa[a] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(sW + (tap * NCT * 16 + r) * CB + (((ks * 4 + lq) ^ sm_swz<CB>(r)) << 4)));
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const int P = ST == 1 ? (wave * 2 + r + tr) * HW + tq + lp
-                                : (((tr & 1) << 1) | (tq & 1)) * PP + (wave * 2 + r + (tr >> 1)) * HW + (tq >> 1) + lp;
+          const int P = ST == 1 ? (wr * 2 + r + tr) * HW + tq + lp
+                                : (((tr & 1) << 1) | (tq & 1)) * PP + (wr * 2 + r + (tr >> 1)) * HW + (tq >> 1) + lp;
           fb[r] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hb + P * CB + (((ks * 4 + lq) ^ sm_swz<CB>(P)) << 4)));
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-          for (int a = 0; a < NCT; ++a) acc[r][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[r], acc[r][a], 0, 0, 0);
+          for (int a = 0; a < NCW; ++a) acc[r][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[r], acc[r][a], 0, 0, 0);
       }
     }
     // lane: pixel (y0 + 2 wave + r, x0 + lp), output channels 16 a + 4 lq .. + 3
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int yy = y0 + wave * 2 + r, xx = x0 + lp;
+      const int yy = y0 + wr * 2 + r, xx = x0 + lp;
       const bool inb = (yy < p.H) & (xx < p.W);
       const unsigned pix = (unsigned)((b * p.H + yy) * p.W + xx) * (unsigned)p.ysw;
 #pragma unroll
-      for (int a = 0; a < NCT; ++a) {
-        const int co = a * 16 + 4 * lq;
+      for (int a = 0; a < NCW; ++a) {
+        const int co = (wc * NCW + a) * 16 + 4 * lq;
         float v[4];
         if (AFF) {
           // (the residual is an ordinary load: the compiler waits vmcnt(0) for it, draining the halo prefetch - shortcut blocks only)
@@ -213,15 +221,15 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   sm_wvm<0>();
   if (p.part) {
     __syncthreads();
-    float* red = (float*)sH;  // [4 waves][NCT * 16][2]
+    float* red = (float*)sH;  // [4 row pairs][NCT * 16][2]
 #pragma unroll
-    for (int a = 0; a < NCT; ++a)
+    for (int a = 0; a < NCW; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float s = wave_xor_sum16(ssum[a][j]), q = wave_xor_sum16(ssq[a][j]);
         if (lp == 0) {
-          red[(wave * NCT * 16 + a * 16 + 4 * lq + j) * 2] = s;
-          red[(wave * NCT * 16 + a * 16 + 4 * lq + j) * 2 + 1] = q;
+          red[(wr * NCT * 16 + (wc * NCW + a) * 16 + 4 * lq + j) * 2] = s;
+          red[(wr * NCT * 16 + (wc * NCW + a) * 16 + 4 * lq + j) * 2 + 1] = q;
         }
       }
     __syncthreads();
@@ -236,20 +244,25 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmP p) {
   }
 }
 
+// (two channel tiles split over eight waves leave a wave one tile: 1 + 2 fragment reads for 2 MFMAs - measured slower, 32.8 against 30.0 us at
+// 32 -> 32 @160x160; four tiles gain: 33.5 -> 27.9 us at 64 -> 64 @80x80 in the training step, 37.2 -> 29.7 us in eval)
+constexpr int sm_waves(int nct) { return nct == 4 ? 8 : 4; }
 constexpr size_t sm_lds(int cb, int nct, int st) {
-  const int spi = 1024 / cb, ninst = ((st == 1 ? 180 : 612) + spi - 1) / spi, ni = (ninst + 3) / 4;
-  return (size_t)9 * nct * 16 * cb + 2 * (size_t)ni * 4 * 1024;
+  const int nw = sm_waves(nct);
+  const int spi = 1024 / cb, ninst = ((st == 1 ? 180 : 612) + spi - 1) / spi, ni = (ninst + nw - 1) / nw;
+  return (size_t)9 * nct * 16 * cb + 2 * (size_t)ni * nw * 1024;
 }
 
 template <int CB, int NCT, bool AFF, int ST = 1>
 void sm_launch(const SmP& p, int grid, hipStream_t st) {
+  constexpr int NW = sm_waves(NCT);
   const size_t lds = sm_lds(CB, NCT, ST);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT, AFF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv3x3_small_kernel<CB, NCT, AFF, ST, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT, AFF, ST>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_small_kernel<CB, NCT, AFF, ST, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
 }
 
 }  // namespace
@@ -265,7 +278,7 @@ int y3d_conv3x3_small_ok(int dtype, int B, int H, int W, int Cin, int Cout, int 
 // workgroups (= rows of BatchNorm partials) for this shape
 int y3d_conv3x3_small_rows(int B, int H, int W, int Cin, int Cout) {
   const int nct = cdiv(Cout, 16), cb = Cin <= 32 ? 64 : 128;  // bytes of an LDS row
-  const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
+  const size_t lds = sm_lds(cb, nct, 1);
   const long ntiles = (long)B * cdiv(H, 8) * cdiv(W, 16);
   const long grid = 256 * (lds <= 80 * 1024 ? 2 : 1);
   return (int)(grid < ntiles ? grid : ntiles);
@@ -291,8 +304,6 @@ int y3d_conv3x3_small_launch(const void* x, long xsb, long xsh, long xsw, int B,
   p.xbytes = (unsigned)xext; p.ybytes = (unsigned)yext;
   const int nct = cdiv(Cout, 16);
   const int cb = Cin <= 32 ? 64 : 128;
-  const size_t lds = (size_t)9 * nct * 16 * cb + 2 * (size_t)(cb == 128 ? 6 : 3) * 4 * 1024;
-  (void)lds;
   const int grid = y3d_conv3x3_small_rows(B, H, W, Cin, Cout);
   Y3D_CHECK(!part || rows == grid, "conv3x3_small: the partial buffer must have y3d_conv2d_stat_rows rows (%d given, %d written)", rows, grid);
   hipStream_t st = (hipStream_t)stream;
